@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fastmax attention forward (p=1, masked) at N=4096, d=64 on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic (B,H,N,D) = (16,32,4096,64) float32
+Q/K/V per GPU, already resident in HBM.  The batch dimension shards over ranks (every (b,h) pair is
+independent): there is NO data-path collective; ranks only meet at the barriers that
+bracket the timed region ("scaling": "weak" -- per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+
+roofline.achieved = algorithmic bytes per launch / mean launch duration, where algorithmic bytes =
+4*B*H*N*D*sizeof(dtype) (read Q,K,V once, write O once) and the duration is measured
+with HIP events on the stream the kernel is launched on (torch's current stream).
+cpu_baseline (rank 0, N=1 only) times the CPU oracle on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch B")
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--p", type=int, default=1)
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "fwd+bwd"])
+    ap.add_argument("--op", default="fastmax", choices=["fastmax", "linearmax"])
+    ap.add_argument("--path", default="auto", choices=["auto", "quadratic", "recurrent", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seconds):
+    """Time the CPU oracle on a bounded sample of the headline workload (reported baseline only).
+
+    'value' is the reference-equivalent restatement (materialise the (N,D,D) outer products and
+    torch.cumsum them, as attention_mechanisms/fastmax.py:236-248 does) with all host threads on
+    (1,4,N,D); the streaming plain-C port is reported beside it."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, fastmax_oracle as orc
+    N, D = args.seq, args.dim
+    nt = 8.0 * (D ** 0.5)
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(1, 4, N, D, generator=g) for _ in range(3))
+    with torch.no_grad():
+        orc.fastmax_fwd_reference_equivalent(q, k, v, nt, p=args.p)        # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.fastmax_fwd_reference_equivalent(q, k, v, nt, p=args.p)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el >= seconds * 0.6 and n >= 3) or el > 3 * seconds:
+                break
+    ref_equiv = n * 1 * N / el
+    # streaming C port, OpenMP over heads, 32 heads so every core has work
+    qn, kn, vn = (np.random.default_rng(1).standard_normal((1, 32, N, D)).astype(np.float32) for _ in range(3))
+    c_oracle.fwd(qn, kn, vn, p=args.p)
+    n2, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.fwd(qn, kn, vn, p=args.p)
+        n2 += 1
+        el2 = time.perf_counter() - t0
+        if (el2 >= seconds * 0.4 and n2 >= 2) or el2 > 3 * seconds:
+            break
+    return {
+        "value": round(ref_equiv, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"oracle.fastmax_fwd_reference_equivalent (outer-product + cumsum, torch CPU ops, fp32) on "
+                  f"(B,H,N,D)=(1,4,{N},{D}) p={args.p} masked, {n} runs in {el:.1f}s; tokens = B*N per run",
+        "head_tokens_per_s": round(ref_equiv * 4, 1),
+        "streaming_c_port": {"value": round(n2 * N / el2, 1), "unit": "tokens/s at H=32",
+                             "head_tokens_per_s": round(n2 * 32 * N / el2, 1),
+                             "cores": c_oracle.max_threads(),
+                             "sample": f"oracle/fastmax_oracle.c (carried-state recurrence, fp64 accumulate, OpenMP over "
+                                       f"heads) on (1,32,{N},{D}), {n2} runs in {el2:.1f}s"},
+        "host_cpu_count": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the fastmax operator has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # RCCL on ROCm; used for the barriers only
+
+    from attention_mechanisms.fastmax import fastmax
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    from fastmax_experiments_amd import _lib, ops
+    _lib.lib()
+    ops.set_forced_path({"auto": 0, "quadratic": 1, "recurrent": 2, "mfma": 3}[args.path])
+
+    B, H, N, D = args.batch, args.heads, args.seq, args.dim
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    q, k, v = (torch.randn(B, H, N, D, device=dev, generator=gen).to(tdt) for _ in range(3))
+    train = args.mode == "fwd+bwd"
+    if train:
+        go = torch.randn(B, H, N, D, device=dev, generator=gen).to(tdt)
+        q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+
+    def step():
+        if args.op == "linearmax":
+            o = fastmax_hack(q, k, v, p=args.p, mask=True)
+        else:
+            o = fastmax(q, k, v, mask=True, p=args.p)
+        if train:
+            q.grad = k.grad = v.grad = None
+            o.backward(go)
+        return o
+
+    path = _lib.PATH_NAMES.get(ops.selected_path(q, k, args.p, True), "?")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # mean device-side duration of one launch of the hot kernel (HIP events on the launch stream)
+    kernel_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps
+
+    if rank == 0:
+        es = {"f32": 4, "bf16": 2, "f16": 2}[args.dtype]
+        alg_bytes = (4 if not train else 4 + 8) * B * H * N * D * es     # fwd: Q,K,V in + O out; bwd adds Q,K,V,O,G in + dQ,dK,dV out
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf) and not train and args.dtype == "f32" and args.p == 1 and args.op == "fastmax" \
+                and (B, H, N, D) == (16, 32, 4096, 64):
+            try:
+                traffic = json.load(open(tf)).get(path, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "fastmax attn tokens/sec + achieved HBM GB/s at N=4096 d=64",
+            "value": round(world * B * N * args.steps / elapsed, 1),
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.op} p={args.p} masked {args.mode}, (B,H,N,D)=({B},{H},{N},{D}) per GPU, "
+                                   f"q,k,v~N(0,1) seed=rank, {args.dtype} I/O, fp32 accumulate",
+                       "B_per_gpu": B, "H": H, "N": N, "D": D, "global_batch": B * world,
+                       "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_path": path},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kernel_ms, 4),
+                         "head_tokens_per_s": round(B * H * N / (kernel_ms * 1e-3), 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

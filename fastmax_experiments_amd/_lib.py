@@ -1,0 +1,79 @@
+"""ctypes binding of the C ABI declared in include/fastmax_hip.h.
+
+Fails loudly: if libfastmax_hip.so is absent or a symbol is missing, importing the operator
+raises -- there is no eager/PyTorch/CPU fallback for the hot path.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfastmax_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+PATH_AUTO, PATH_QUADRATIC, PATH_RECURRENT, PATH_MFMA = 0, 1, 2, 3
+PATH_NAMES = {PATH_AUTO: "auto", PATH_QUADRATIC: "quadratic", PATH_RECURRENT: "recurrent", PATH_MFMA: "mfma"}
+E_BAD_P = -1
+
+# every symbol include/fastmax_hip.h declares
+SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_backward_workspace",
+           "fastmax_hip_backward", "fastmax_hip_normalize_workspace", "fastmax_hip_normalize",
+           "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string"]
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("H", ctypes.c_int), ("Nq", ctypes.c_int), ("Nk", ctypes.c_int),
+                ("D", ctypes.c_int), ("in_dtype", ctypes.c_int), ("out_dtype", ctypes.c_int), ("p", ctypes.c_int),
+                ("causal", ctypes.c_int), ("a", ctypes.c_float), ("b", ctypes.c_float), ("g0", ctypes.c_float),
+                ("path", ctypes.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m fastmax_experiments_amd.build` "
+            "(hipcc, --offload-arch=gfx950). The fastmax operator has no fallback path.")
+    L = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(L, s):
+            raise RuntimeError(f"libfastmax_hip.so does not export {s}")
+    vp, i64p, fp, sz, ci = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    pp = ctypes.POINTER(Problem)
+    L.fastmax_hip_forward_workspace.argtypes = [pp]
+    L.fastmax_hip_forward_workspace.restype = sz
+    L.fastmax_hip_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, sz, vp]
+    L.fastmax_hip_forward.restype = ci
+    L.fastmax_hip_backward_workspace.argtypes = [pp]
+    L.fastmax_hip_backward_workspace.restype = sz
+    L.fastmax_hip_backward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, i64p, vp, vp, vp, vp, sz, vp]
+    L.fastmax_hip_backward.restype = ci
+    L.fastmax_hip_normalize_workspace.argtypes = [ci, ci]
+    L.fastmax_hip_normalize_workspace.restype = sz
+    L.fastmax_hip_normalize.argtypes = [vp, i64p, ci, fp, fp, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize.restype = ci
+    L.fastmax_hip_abi_version.restype = ci
+    L.fastmax_hip_select_path.argtypes = [pp]
+    L.fastmax_hip_select_path.restype = ci
+    L.fastmax_hip_error_string.argtypes = [ci]
+    L.fastmax_hip_error_string.restype = ctypes.c_char_p
+    if L.fastmax_hip_abi_version() != 1:
+        raise RuntimeError("libfastmax_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def error_string(code):
+    return lib().fastmax_hip_error_string(int(code)).decode()
+
+
+def check(code, what):
+    if code == 0:
+        return
+    if code == E_BAD_P:
+        raise ValueError(f"{what}: {error_string(code)}")
+    raise RuntimeError(f"{what} failed: rc={code} ({error_string(code)})")

@@ -1,0 +1,78 @@
+"""Drop-in for the reference's ``attention_mechanisms/fastmax_hack.py`` ("linearmax").
+
+Reference: fastmax_hack.py:5-60.  Masked branch (36-60): mean-centre / max-norm Q and K, then
+first- or second-order fastmax with normalize_term = 1.  Unmasked branch (6-33): same prologue,
+first order only (``p`` is ignored there), denominator constant N_k (line 21), float32 ``ones``
+promote low-precision inputs to a float32 result.
+The prologue and the attention both run in libfastmax_hip.so; gradients flow through
+``_NormalizeQK`` (the reference gets them from plain autograd over its einsum graph).
+"""
+import torch
+
+from .. import ops
+from .fastmax import _KERNEL_DTYPES, fastattention_einops
+
+
+class _NormalizeQK(torch.autograd.Function):
+    """y = (x - mean_D x) / max_n ||x_n - mean_D x_n||   (fastmax_hack.py:38-43), float32 out."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.normalize(x)
+        ctx.save_for_backward(y, inv)
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, inv = ctx.saved_tensors                     # y = xc / M, inv = 1 / M
+        gy = gy.float()
+        gxc = gy * inv[..., None, None]
+        # M = max_n ||xc_n|| is attained at token n*: dM/dxc_{n*} = xc_{n*}/M = y_{n*};  dL/dM = -sum(gy*y)/M
+        dLdM = -(gy * y).sum(dim=(2, 3)) * inv                                    # (B,H)
+        nstar = (y * y).sum(-1).argmax(dim=2)                                      # (B,H)
+        ystar = torch.gather(y, 2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]))
+        gxc.scatter_add_(2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]), dLdM[..., None, None] * ystar)
+        gx = gxc - gxc.mean(-1, keepdim=True)
+        return gx.to(ctx.in_dtype)
+
+
+def fastmax_hack(q, k, v, p=1, mask=True):
+    """linearmax (reference: fastmax_hack.py:5)."""
+    dev = ops._device() if q.device.type != "cuda" else q.device
+    home, in_dtype = q.device, q.dtype
+    kdt = in_dtype if in_dtype in _KERNEL_DTYPES else torch.float32
+    qd, kd = (ops._prep(t.to(kdt), dev) for t in (q, k))
+    vd = v.to(device=dev, dtype=torch.float32)
+    qn, kn = _NormalizeQK.apply(qd), _NormalizeQK.apply(kd)
+    if not mask:
+        # fastmax_hack.py:6-33: first order whatever p is; constant term N_k; result float32 for
+        # low-precision inputs (float32 ones at line 21), float64 stays float64
+        o = _unmasked_first_order(qn, kn, vd, float(k.shape[2]))
+        out_dt = torch.float64 if in_dtype == torch.float64 else torch.float32
+    else:
+        o = fastattention_einops.apply(qn, kn, vd, True, 1, True, p, 0.0, False)
+        out_dt = in_dtype
+    return o.to(device=home, dtype=out_dt)
+
+
+class _UnmaskedNk(torch.autograd.Function):
+    """Unmasked p=1 fastmax with nt=1 and the denominator constant g0 = N_k (fastmax_hack.py:17-31)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, g0):
+        o, g = ops.forward(ops._prep(q, q.device), ops._prep(k, q.device), ops._prep(v, q.device), 1, False, 1.0,
+                           g0, torch.float32)
+        ctx.save_for_backward(q, k, v, o, g)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o, g = ctx.saved_tensors
+        dq, dk, dv = ops.backward(ops._prep(q, q.device), ops._prep(k, q.device), ops._prep(v, q.device), o, g,
+                                  ops._prep(go.float(), q.device), 1, False, 1.0)
+        return dq, dk, dv, None
+
+
+def _unmasked_first_order(qn, kn, v, g0):
+    return _UnmaskedNk.apply(qn, kn, v, g0)

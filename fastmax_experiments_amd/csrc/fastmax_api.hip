@@ -1,0 +1,119 @@
+// extern "C" entry points of libfastmax_hip.so (see include/fastmax_hip.h) + path selection.
+#include "fastmax_common.h"
+
+using namespace fastmax;
+
+namespace {
+int validate(const fastmax_problem* p) {
+    if (!p) return FASTMAX_E_NULL;
+    if (p->p != 1 && p->p != 2) return FASTMAX_E_BAD_P;
+    if (p->B <= 0 || p->H <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->D <= 0 || p->D > FASTMAX_MAX_D)
+        return FASTMAX_E_BAD_SHAPE;
+    if (p->causal && p->Nq != p->Nk) return FASTMAX_E_BAD_SHAPE;
+    if (p->in_dtype < 0 || p->in_dtype > 2 || p->out_dtype < 0 || p->out_dtype > 2) return FASTMAX_E_BAD_DTYPE;
+    return FASTMAX_OK;
+}
+Strides3 st(const int64_t* s) { return Strides3{s[0], s[1], s[2]}; }
+
+int select(const fastmax_problem& p) {
+    if (p.path == FASTMAX_PATH_QUADRATIC) return FASTMAX_PATH_QUADRATIC;
+    const bool lin = (p.p == 1 && p.causal);
+    if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
+    if (p.path == FASTMAX_PATH_MFMA) return (lin && mfma_p1_supported(p)) ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
+    if (lin) return mfma_p1_supported(p) ? FASTMAX_PATH_MFMA : FASTMAX_PATH_RECURRENT;
+    return FASTMAX_PATH_QUADRATIC;
+}
+bool aligned16(const void* ptr, const int64_t* s, int dtype) {
+    const int64_t es = dtype == FASTMAX_F32 ? 4 : 2;
+    if (reinterpret_cast<uintptr_t>(ptr) & 15) return false;
+    for (int i = 0; i < 3; ++i)
+        if ((s[i] * es) & 15) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int fastmax_hip_abi_version(void) { return FASTMAX_ABI_VERSION; }
+
+const char* fastmax_hip_error_string(int code) {
+    switch (code) {
+        case FASTMAX_OK: return "ok";
+        case FASTMAX_E_BAD_P: return "p should be 1 or 2";
+        case FASTMAX_E_BAD_SHAPE: return "bad shape (sizes must be positive, causal needs Nq == Nk, D <= 128) or path not applicable";
+        case FASTMAX_E_BAD_DTYPE: return "bad dtype";
+        case FASTMAX_E_WORKSPACE: return "workspace missing or too small";
+        case FASTMAX_E_ALIGNMENT: return "pointer / stride alignment";
+        case FASTMAX_E_NULL: return "null pointer";
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}
+
+int fastmax_hip_select_path(const fastmax_problem* prob) {
+    const int rc = validate(prob);
+    if (rc) return rc;
+    return select(*prob);
+}
+
+size_t fastmax_hip_forward_workspace(const fastmax_problem* prob) {
+    if (validate(prob)) return 0;
+    return select(*prob) == FASTMAX_PATH_MFMA ? mfma_p1_workspace(*prob) : 0;
+}
+
+int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                        const int64_t* k_strides, const void* v, const int64_t* v_strides, void* o, float* g,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = validate(prob);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides) return FASTMAX_E_NULL;
+    int path = select(*prob);
+    if (path < 0) return path;
+    if (path == FASTMAX_PATH_MFMA) {
+        const bool ok = aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
+                        aligned16(v, v_strides, prob->in_dtype) && !(reinterpret_cast<uintptr_t>(o) & 15);
+        if (!ok) {
+            if (prob->path == FASTMAX_PATH_MFMA) return FASTMAX_E_ALIGNMENT;
+            path = FASTMAX_PATH_RECURRENT;
+        }
+    }
+    FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
+              reinterpret_cast<hipStream_t>(stream)};
+    switch (path) {
+        case FASTMAX_PATH_MFMA: return launch_fwd_mfma_p1(a);
+        case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
+        default: return launch_fwd_quadratic(a);
+    }
+}
+
+size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
+    if (validate(prob)) return 0;
+    return bwd_quadratic_workspace(*prob);
+}
+
+int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                         const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o,
+                         const float* g, const void* grad_o, const int64_t* go_strides, void* dq, void* dk, void* dv,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = validate(prob);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !g || !grad_o || !dq || !dk || !dv || !q_strides || !k_strides || !v_strides ||
+        !go_strides)
+        return FASTMAX_E_NULL;
+    BwdArgs a{*prob, q, k, v, o, grad_o, g, st(q_strides), st(k_strides), st(v_strides), st(go_strides), dq, dk, dv,
+              workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
+    return launch_bwd_quadratic(a);
+}
+
+size_t fastmax_hip_normalize_workspace(int B, int H) { return sizeof(unsigned int) * (size_t)B * H; }
+
+int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype, float* y, float* inv_norm, int B, int H,
+                          int N, int D, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !x_strides || !y) return FASTMAX_E_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
+    return launch_normalize(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, workspace,
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

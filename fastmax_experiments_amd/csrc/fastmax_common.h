@@ -1,0 +1,108 @@
+// Shared device helpers for the fastmax HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/fastmax_hip.h"
+
+namespace fastmax {
+
+// ---- element types ---------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+struct f16_t { _Float16 v; };
+
+__device__ __forceinline__ float to_float(float x) { return x; }
+__device__ __forceinline__ float to_float(bf16_t x) { return __uint_as_float(((uint32_t)x.bits) << 16); }
+__device__ __forceinline__ float to_float(f16_t x) { return (float)x.v; }
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    // round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 (NaN stays NaN)
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<uint16_t*>(&h);
+}
+template <typename T> __device__ __forceinline__ T from_float(float f);
+template <> __device__ __forceinline__ float from_float<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_float<bf16_t>(float f) { return bf16_t{f32_to_bf16_bits(f)}; }
+template <> __device__ __forceinline__ f16_t from_float<f16_t>(float f) { return f16_t{(_Float16)f}; }
+
+// ---- strided (B,H,N,D) view ------------------------------------------------------
+struct View {
+    const void* ptr;
+    int64_t sb, sh, sn;   // element strides; D has stride 1
+};
+struct Strides3 { int64_t sb, sh, sn; };
+
+template <typename T>
+__device__ __forceinline__ const T* row_ptr(const void* base, int64_t sb, int64_t sh, int64_t sn, int b, int h,
+                                            int n) {
+    return reinterpret_cast<const T*>(base) + (int64_t)b * sb + (int64_t)h * sh + (int64_t)n * sn;
+}
+
+// ---- wave helpers (wave = 64 lanes) ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+// inclusive prefix sum across the 64 lanes of a wave (Hillis-Steele on __shfl_up)
+__device__ __forceinline__ float wave_inclusive_scan(float x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+template <int P> __device__ __forceinline__ float poly_f(float s) {
+    if constexpr (P == 1) return 1.0f + s;
+    else return 1.0f + s + 0.5f * s * s;
+}
+template <int P> __device__ __forceinline__ float poly_fprime(float s) {
+    if constexpr (P == 1) return 1.0f;
+    else return 1.0f + s;
+}
+
+}  // namespace fastmax
+
+// ---- host-side launchers implemented in the .hip files ------------------------------
+namespace fastmax {
+struct FwdArgs {
+    fastmax_problem prob;
+    const void *q, *k, *v;
+    Strides3 qs, ks, vs;
+    void* o;
+    float* g;
+    void* workspace;
+    size_t workspace_bytes;
+    hipStream_t stream;
+};
+struct BwdArgs {
+    fastmax_problem prob;
+    const void *q, *k, *v, *o, *grad_o;
+    const float* g;
+    Strides3 qs, ks, vs, gos;
+    void *dq, *dk, *dv;
+    void* workspace;
+    size_t workspace_bytes;
+    hipStream_t stream;
+};
+
+int launch_fwd_quadratic(const FwdArgs& a);
+int launch_fwd_recurrent_p1(const FwdArgs& a);
+int launch_fwd_mfma_p1(const FwdArgs& a);
+bool mfma_p1_supported(const fastmax_problem& p);
+size_t mfma_p1_workspace(const fastmax_problem& p);
+int launch_bwd_quadratic(const BwdArgs& a);
+size_t bwd_quadratic_workspace(const fastmax_problem& p);
+int launch_normalize(const void* x, Strides3 xs, int dtype, float* y, float* inv_norm, int B, int H, int N, int D,
+                     void* workspace, hipStream_t stream);
+}  // namespace fastmax

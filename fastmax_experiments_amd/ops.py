@@ -1,0 +1,121 @@
+"""Host side of the fastmax operator: tensor plumbing around the C ABI (include/fastmax_hip.h).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; all arithmetic of
+the hot path runs in libfastmax_hip.so.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+_force_path = _lib.PATH_AUTO
+
+
+def set_forced_path(path):
+    """Testing / benchmarking hook: force a kernel family (``_lib.PATH_*``); AUTO restores dispatch."""
+    global _force_path
+    _force_path = int(path)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("fastmax needs an MI355X (HIP device); there is no CPU fallback for this operator")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _prep(t, dev):
+    """-> tensor on the HIP device with unit stride in D and 16-byte aligned rows."""
+    if t.device.type != "cuda":
+        t = t.to(dev, non_blocking=False)
+    es = t.element_size()
+    ok = t.stride(3) == 1 and all((s * es) % 16 == 0 for s in t.stride()[:3]) and t.data_ptr() % 16 == 0
+    return t if ok else t.contiguous()
+
+
+def _strides(t):
+    return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ws(nbytes, dev):
+    if nbytes == 0:
+        return None, ctypes.c_void_p(0)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf, ctypes.c_void_p(buf.data_ptr())
+
+
+def _problem(q, k, in_dt, out_dt, p, causal, nt, g0):
+    B, H, Nq, D = q.shape
+    return _lib.Problem(B, H, Nq, k.shape[2], D, _DT[in_dt], _DT[out_dt], int(p), int(causal), 1.0 / nt,
+                        1.0 / (2.0 * nt * nt), float(g0), _force_path)
+
+
+def selected_path(q, k, p, causal, nt=1.0):
+    prob = _problem(q, k, q.dtype if q.dtype in _DT else torch.float32, torch.float32, p, causal, nt, 0.0)
+    return _lib.lib().fastmax_hip_select_path(ctypes.byref(prob))
+
+
+def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True):
+    """q,k,v: device tensors (B,H,N,D) of one dtype in {f32,bf16,f16}. -> (o, g)"""
+    L = _lib.lib()
+    if p not in (1, 2):
+        raise ValueError(f"p should be 1 or 2, got p={p}")
+    dev = q.device
+    B, H, Nq, D = q.shape
+    if D > 128:
+        raise NotImplementedError(f"head size {D} > 128 is not supported by the HIP kernels")
+    prob = _problem(q, k, q.dtype, out_dtype, p, causal, nt, g0)
+    o = torch.empty((B, H, Nq, D), dtype=out_dtype, device=dev)
+    g = torch.empty((B, H, Nq), dtype=torch.float32, device=dev) if need_g else None
+    wsb, wsp = _ws(L.fastmax_hip_forward_workspace(ctypes.byref(prob)), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_forward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                   v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr() if need_g else None,
+                                   wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
+    _lib.check(rc, "fastmax_hip_forward")
+    return o, g
+
+
+def backward(q, k, v, o, g, grad_o, p, causal, nt):
+    L = _lib.lib()
+    dev = q.device
+    prob = _problem(q, k, q.dtype, o.dtype, p, causal, nt, 0.0)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=dev)
+    dk = torch.empty(k.shape, dtype=q.dtype, device=dev)
+    dv = torch.empty(v.shape, dtype=q.dtype, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_backward_workspace(ctypes.byref(prob)), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_backward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                    v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr(), grad_o.data_ptr(),
+                                    _strides(grad_o), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), wsp,
+                                    wsb.numel() if wsb is not None else 0, _stream(dev))
+    _lib.check(rc, "fastmax_hip_backward")
+    return dq, dk, dv
+
+
+def normalize(x):
+    """linearmax prologue on the device. x: (B,H,N,D) -> (y float32 contiguous, inv_norm (B,H) float32)."""
+    L = _lib.lib()
+    dev = x.device
+    B, H, N, D = x.shape
+    if D > 128:
+        raise NotImplementedError(f"head size {D} > 128 is not supported by the HIP kernels")
+    y = torch.empty((B, H, N, D), dtype=torch.float32, device=dev)
+    inv = torch.empty((B, H), dtype=torch.float32, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_workspace(B, H), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_normalize(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H, N,
+                                     D, wsp, wsb.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_normalize")
+    return y, inv
+
+
+def effective_normalize_term(D, normalize_term, tensors_normalized):
+    # attention_mechanisms/fastmax.py:78-82
+    return 1.0 if tensors_normalized is True else normalize_term * math.sqrt(D)

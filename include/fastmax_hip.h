@@ -1,0 +1,116 @@
+/* fastmax_hip.h -- C ABI of libfastmax_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for the reference's fastmax / linearmax operator.  The
+ * reference is pure Python: there is no pre-existing C/FFI interface for this path (the
+ * `fastmax_cuda.forwardpass/backwardpass` extension declared at setup_fast_cuda.py:24-34
+ * and called at lit_gpt/model.py:82-84,116 has no sources in the repo and is a different,
+ * RPE-bearing op).  Each entry point therefore cites the PYTHON function whose arithmetic
+ * it replaces; the Python shim that binds them (ctypes) lives in
+ * fastmax_experiments_amd/_lib.py and keeps the reference's call signatures.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless stated
+ *   - no allocation, no host synchronisation inside: the caller owns all buffers and
+ *     the call is stream-ordered on `stream` (a hipStream_t passed as void*)
+ *   - tensors are (B,H,N,D); `*_strides` are ELEMENT strides of the b, h, n dims
+ *     (3 x int64, host memory); the D dim must have stride 1 and each row must start
+ *     16-byte aligned (the Python shim copies anything else to contiguous first)
+ *   - outputs are contiguous (B,H,N,D) / (B,H,N)
+ *   - return 0 on success, a negative FASTMAX_E_* code on a rejected call, or a positive
+ *     hipError_t if a launch failed
+ */
+#ifndef FASTMAX_HIP_H
+#define FASTMAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTMAX_ABI_VERSION 1
+
+enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
+
+enum fastmax_error {
+    FASTMAX_OK = 0,
+    FASTMAX_E_BAD_P = -1,        /* p not in {1,2}: the Python shim raises ValueError like fastmax.py:362,428 */
+    FASTMAX_E_BAD_SHAPE = -2,    /* non-positive size, causal with Nq != Nk, D > FASTMAX_MAX_D */
+    FASTMAX_E_BAD_DTYPE = -3,
+    FASTMAX_E_WORKSPACE = -4,    /* workspace missing or too small */
+    FASTMAX_E_ALIGNMENT = -5,    /* a base pointer or a stride breaks the 16-byte row alignment rule */
+    FASTMAX_E_NULL = -6
+};
+
+#define FASTMAX_MAX_D 128
+
+/* Which kernel family a call would use; for tests and the benchmark report. */
+enum fastmax_path {
+    FASTMAX_PATH_AUTO = 0,
+    FASTMAX_PATH_QUADRATIC = 1,  /* masked/unmasked f(QK^T)V tiles on the vector ALU, any p, any D<=128 */
+    FASTMAX_PATH_RECURRENT = 2,  /* p=1 masked, carried K^T V' state, vector ALU, linear in N */
+    FASTMAX_PATH_MFMA = 3        /* p=1 masked, chunked scan on the matrix cores (split-bf16), D in {32,64,128} */
+};
+
+typedef struct fastmax_problem {
+    int B, H, Nq, Nk, D;
+    int in_dtype;    /* enum fastmax_dtype of q,k,v (and grad_o)                       */
+    int out_dtype;   /* enum fastmax_dtype of o (and dq,dk,dv); see dtype rule Q1       */
+    int p;           /* 1 or 2: degree of the Taylor polynomial f                       */
+    int causal;      /* 1 = `mask=True` of the reference (j <= i), needs Nq == Nk       */
+    float a;         /* 1/nt          (nt: fastmax.py:78-82)                            */
+    float b;         /* 1/(2 nt^2)    (used when p == 2)                                */
+    float g0;        /* constant term of the denominator when causal == 0:
+                        Nq for fastmax.py:269-271, Nk for fastmax_hack.py:21            */
+    int path;        /* enum fastmax_path; FASTMAX_PATH_AUTO lets the library choose    */
+} fastmax_problem;
+
+/* ---- forward: replaces fastattention_einops.forward's F/g computation
+ *      (attention_mechanisms/fastmax.py:84-97; compute_F_* 184-250, compute_g_* 252-322).
+ *      o: (B,H,Nq,D) out_dtype.  g: (B,H,Nq) float32 denominator, saved for backward
+ *      (fastmax.py:106); may be NULL when the caller does not need it.                   */
+size_t fastmax_hip_forward_workspace(const fastmax_problem* prob);
+int fastmax_hip_forward(const fastmax_problem* prob,
+                        const void* q, const int64_t* q_strides,
+                        const void* k, const int64_t* k_strides,
+                        const void* v, const int64_t* v_strides,
+                        void* o, float* g,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- backward: replaces fastattention_einops.backward (fastmax.py:113-182) and the six
+ *      gradient_o_{q,k,v}_{masked,unmasked} (383-691).  o, g: the forward's outputs.
+ *      o: contiguous (B,H,Nq,D) in out_dtype.  grad_o: (B,H,Nq,D) in_dtype, strides as given.
+ *      dq:(B,H,Nq,D) dk,dv:(B,H,Nk,D) contiguous, in_dtype (autograd hands each gradient
+ *      back in the dtype of the input it belongs to).                                    */
+size_t fastmax_hip_backward_workspace(const fastmax_problem* prob);
+int fastmax_hip_backward(const fastmax_problem* prob,
+                         const void* q, const int64_t* q_strides,
+                         const void* k, const int64_t* k_strides,
+                         const void* v, const int64_t* v_strides,
+                         const void* o, const float* g,
+                         const void* grad_o, const int64_t* go_strides,
+                         void* dq, void* dk, void* dv,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- linearmax prologue: replaces fastattention_einops.normalize (fastmax.py:326-334)
+ *      == the inline copy at fastmax_hack.py:38-43 / 10-15: per token subtract the mean
+ *      over D, then divide the (b,h) slab by the max over tokens of the per-token L2 norm.
+ *      x: (B,H,N,D) in `dtype`, strides given; y: contiguous (B,H,N,D) float32;
+ *      inv_norm: (B,H) float32 = 1/max-norm (kept for the backward of the prologue).
+ *      workspace: B*H floats.                                                            */
+size_t fastmax_hip_normalize_workspace(int B, int H);
+int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype,
+                          float* y, float* inv_norm, int B, int H, int N, int D,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- introspection */
+int fastmax_hip_abi_version(void);
+/* path a problem would take under FASTMAX_PATH_AUTO (enum fastmax_path), <0 on a bad problem */
+int fastmax_hip_select_path(const fastmax_problem* prob);
+const char* fastmax_hip_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTMAX_HIP_H */

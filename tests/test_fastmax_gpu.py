@@ -1,0 +1,278 @@
+"""Parity tests proper: the HIP path (through the reference's Python signature -> ctypes -> C ABI)
+against the golden vectors from the reference and against the CPU oracle.  Need an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+# float32 kernels accumulate in fp32 (the matrix-core path in split-bf16, ~16 mantissa bits per
+# product); the north star asks for 1e-3 relative -- the tests hold the fp32 paths to 2e-4 / 1e-3
+TOL_FWD = 2e-4
+TOL_BWD = 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from fastmax_experiments_amd import _lib
+    _lib.lib()          # fail loudly if the extension is missing
+
+
+def _t(x, dtype=torch.float32, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dtype)
+    return t.requires_grad_(grad)
+
+
+def _kw(meta):
+    return dict(meta.get("kw", {}))
+
+
+PATHS = ["auto", "quadratic", "recurrent", "mfma"]
+
+
+def _force(path):
+    from fastmax_experiments_amd import _lib, ops
+    ops.set_forced_path({"auto": _lib.PATH_AUTO, "quadratic": _lib.PATH_QUADRATIC,
+                         "recurrent": _lib.PATH_RECURRENT, "mfma": _lib.PATH_MFMA}[path])
+
+
+@pytest.fixture(autouse=True)
+def _restore_path():
+    yield
+    _force("auto")
+
+
+@pytest.mark.parametrize("name", golden_names("fm_") + golden_names("opt_"))
+def test_golden_forward_backward(name):
+    from attention_mechanisms.fastmax import fastmax
+    d, meta = load_golden(name)
+    q, k, v = (_t(d[n], grad=True) for n in "qkv")
+    o = fastmax(q, k, v, mask=meta["mask"], p=meta["p"], **_kw(meta))
+    assert o.dtype == torch.float32 and o.shape == q.shape and o.is_contiguous()
+    assert rel_err(o.detach().cpu().numpy(), d["o"]) < TOL_FWD
+    o.backward(_t(d["grad_o"]))
+    for t, n in ((q, "dq"), (k, "dk"), (v, "dv")):
+        assert rel_err(t.grad.cpu().numpy(), d[n], atol=1e-3) < TOL_BWD, n
+
+
+@pytest.mark.parametrize("path", ["quadratic", "recurrent", "mfma"])
+@pytest.mark.parametrize("name", [n for n in golden_names("fm_") if n.endswith("p1_masked")] +
+                         ["opt_tensors_normalized_p1", "opt_normalize_term_3_p1"])
+def test_golden_forward_each_kernel_family(name, path):
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    d, meta = load_golden(name)
+    q, k, v = (_t(d[n]) for n in "qkv")
+    _force(path)
+    if path == "mfma" and ops.selected_path(q, k, 1, True) != _lib.PATH_MFMA:
+        pytest.skip("matrix-core kernel does not cover this head size")
+    o = fastmax(q, k, v, mask=True, p=1, **_kw(meta))
+    assert rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+def test_c1_baseline_config():
+    from attention_mechanisms.fastmax import fastmax
+    d, _ = load_golden("c1_fastmax_p1_masked_fp32")
+    o = fastmax(*(_t(d[n]) for n in "qkv"))
+    assert rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+def test_stress_large_scores_recorded():
+    # N(0,16) scores: the reference's own fp32 run is ill-conditioned here (1/g amplification);
+    # recorded with a loose bound, as SURVEY 8c prescribes
+    from attention_mechanisms.fastmax import fastmax
+    for name in golden_names("stress_"):
+        d, meta = load_golden(name)
+        o = fastmax(*(_t(d[n]) for n in "qkv"), mask=True, p=meta["p"])
+        assert rel_err(o.cpu().numpy(), d["o"]) < 5e-2
+
+
+def test_noncontiguous_gqa_inputs():
+    from attention_mechanisms.fastmax import fastmax
+    d, _ = load_golden("noncontig_gqa_p1")
+    B, H, N, D = d["q"].shape
+    q = _t(d["q"]).transpose(1, 2).contiguous().transpose(1, 2)       # strided view
+    kg = _t(d["k"][:, ::3])                                            # one row per KV group
+    k = kg[:, :, None].expand(B, H // 3, 3, N, D).reshape(B, H, N, D)
+    v = _t(d["v"])
+    assert not q.is_contiguous()
+    o = fastmax(q, k, v)
+    assert o.is_contiguous() and rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+    # a strided view (every other token of a padded buffer) is consumed in place through the strides
+    qpad = torch.zeros(B, H, 2 * N, D, device="cuda")
+    qpad[:, :, ::2] = _t(d["q"])
+    qs = qpad[:, :, ::2]
+    assert qs.stride(2) == 2 * D
+    o2 = fastmax(qs, k, v)
+    assert rel_err(o2.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("name", golden_names("decode_"))
+def test_unmasked_nq_ne_nk(name):
+    from attention_mechanisms.fastmax import fastmax
+    d, meta = load_golden(name)
+    o = fastmax(*(_t(d[n]) for n in "qkv"), mask=False, p=meta["p"])
+    assert o.shape == d["o"].shape and rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("name", ["hack_masked_p1", "hack_masked_p2", "hack_masked_p1_D128", "hack_unmasked",
+                                  "hack_unmasked_Nq4_Nk16"])
+def test_linearmax_forward(name):
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    d, meta = load_golden(name)
+    o = fastmax_hack(*(_t(d[n]) for n in "qkv"), p=meta["p"], mask=meta["mask"])
+    assert o.dtype == torch.float32 and rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+def test_linearmax_gradients():
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    d, _ = load_golden("hack_masked_p1_grads")
+    q, k, v = (_t(d[n], grad=True) for n in "qkv")
+    o = fastmax_hack(q, k, v, p=1, mask=True)
+    assert rel_err(o.detach().cpu().numpy(), d["o"]) < TOL_FWD
+    o.backward(_t(d["grad_o"]))
+    for t, n in ((q, "dq"), (k, "dk"), (v, "dv")):
+        assert rel_err(t.grad.cpu().numpy(), d[n]) < TOL_BWD, n
+
+
+def test_normalize():
+    from attention_mechanisms.fastmax import fastattention_einops
+    d, _ = load_golden("normalize")
+    qn, kn = fastattention_einops.normalize(_t(d["q"]), _t(d["k"]))
+    assert rel_err(qn.cpu().numpy(), d["qn"]) < 1e-5 and rel_err(kn.cpu().numpy(), d["kn"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", golden_names("create_attn_"))
+def test_create_attn(name, caplog):
+    from attention_mechanisms.fastmax import fastmax
+    d, meta = load_golden(name)
+    o, a = fastmax(*(_t(d[n]) for n in "qkv"), mask=meta["mask"], p=meta["p"], create_attn=True)
+    assert rel_err(a.cpu().numpy(), d["a"]) < 1e-5 and rel_err(o.cpu().numpy(), d["o"]) < 1e-5
+    assert any("compute_attn = True" in r.message for r in caplog.records)
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("mask", [True, False])
+def test_dtype_rules(dt, mask):
+    """Q1: masked keeps the input dtype, unmasked promotes bf16/fp16 to float32.  Values: low-precision
+    kernels are judged against the fp64 ORACLE on the upcast inputs (the reference's own bf16 run
+    accumulates its cumsums in bf16 and is 4.5e-3 off its fp32 self)."""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import fastmax_oracle as orc
+    d, meta = load_golden(f"dtype_{dt}_{'masked' if mask else 'unmasked'}")
+    tdt = getattr(torch, dt)
+    q, k, v = (_t(d[n], tdt) for n in "qkv")
+    o = fastmax(q, k, v, mask=mask, p=1)
+    assert str(o.dtype) == meta["out_dtype"]
+    ref, _ = orc.fastmax_fwd_factorized(*(t.float().cpu().numpy() for t in (q, k, v)), mask=mask, p=1)
+    tol = 2e-4 if o.dtype == torch.float32 else (8e-3 if o.dtype == torch.bfloat16 else 2e-3)
+    assert rel_err(o.float().cpu().numpy(), ref) < tol
+    # and it stays in the neighbourhood of what the reference itself produced in that dtype
+    assert rel_err(o.float().cpu().numpy(), d["o"]) < 2e-2
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_low_precision_backward(dt):
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(3)
+    q, k, v, go = (torch.randn(2, 2, 96, 64, generator=g).to(dt) for _ in range(4))
+    for mask in (True, False):
+        qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = fastmax(qq, kk, vv, mask=mask, p=2)
+        o.backward(go.cuda().to(o.dtype))
+        assert qq.grad.dtype == dt and kk.grad.dtype == dt and vv.grad.dtype == dt
+        e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=2)
+        tol = 2e-2 if dt == torch.bfloat16 else 4e-3
+        for t, r in zip((qq, kk, vv), e):
+            assert rel_err(t.grad.float().cpu().numpy(), r) < tol
+
+
+def test_cpu_tensors_round_trip_like_model_py():
+    # lit_gpt/model.py:482-486 hands CPU tensors over and calls .cuda() on the result
+    from attention_mechanisms.fastmax import fastmax
+    d, _ = load_golden("fm_B1H2N64D64_p2_masked")
+    q, k, v = (torch.from_numpy(d[n]) for n in "qkv")
+    o = fastmax(q, k, v, p=2, mask=True)
+    assert o.device.type == "cpu" and rel_err(o.numpy(), d["o"]) < TOL_FWD
+    assert o.cuda().is_cuda
+
+
+def test_float64_inputs_keep_dtype():
+    from attention_mechanisms.fastmax import fastmax
+    d, _ = load_golden("fm_B1H2N64D32_p1_masked")
+    o = fastmax(*(_t(d[n], torch.float64) for n in "qkv"))
+    assert o.dtype == torch.float64 and rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+def test_bad_p_raises():
+    from attention_mechanisms.fastmax import fastmax
+    q = torch.zeros(1, 1, 4, 8, device="cuda")
+    with pytest.raises(ValueError):
+        fastmax(q, q, q, p=3)
+
+
+@pytest.mark.parametrize("shape,p,mask", [((2, 4, 1024, 64), 1, True), ((1, 3, 1000, 64), 1, True),
+                                          ((1, 2, 777, 128), 1, True), ((2, 2, 513, 32), 1, True),
+                                          ((1, 2, 300, 80), 1, True), ((1, 2, 512, 64), 2, True),
+                                          ((1, 2, 384, 64), 2, False), ((1, 2, 300, 48), 1, False)])
+def test_medium_sizes_vs_c_oracle(shape, p, mask):
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(11)
+    q, k, v, go = (torch.randn(shape, generator=g) for _ in range(4))
+    qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o = fastmax(qq, kk, vv, mask=mask, p=p)
+    ro, _ = c_oracle.fwd(q.numpy(), k.numpy(), v.numpy(), mask=mask, p=p)
+    assert rel_err(o.detach().cpu().numpy(), ro) < TOL_FWD
+    o.backward(go.cuda())
+    e = c_oracle.bwd(q.numpy(), k.numpy(), v.numpy(), go.numpy(), mask=mask, p=p)
+    for t, r, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+        assert rel_err(t.grad.cpu().numpy(), r) < TOL_BWD, n
+
+
+@pytest.mark.parametrize("path", ["recurrent", "mfma"])
+def test_kernel_families_agree_on_ragged_lengths(path):
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(5)
+    for N in (1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 200):
+        q, k, v = (torch.randn(2, 3, N, 64, generator=g) for _ in range(3))
+        _force(path)
+        if path == "mfma" and ops.selected_path(q.cuda(), k.cuda(), 1, True) != _lib.PATH_MFMA:
+            pytest.skip("matrix-core kernel not available for this shape")
+        o = fastmax(q.cuda(), k.cuda(), v.cuda())
+        ro, _ = c_oracle.fwd(q.numpy(), k.numpy(), v.numpy())
+        assert rel_err(o.cpu().numpy(), ro) < TOL_FWD, N
+
+
+def test_full_baseline_shape_properties():
+    """BASELINE shape (16,32,4096,64) fp32, p=1 masked: sampled heads against the C oracle plus
+    size-independent properties -- rows of the implied attention matrix sum to one (v = ones -> o = 1),
+    linearity in V, and causality (changing tokens >= t leaves outputs < t untouched, bit for bit)."""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    B, H, N, D = 16, 32, 4096, 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q, k, v = (torch.randn(B, H, N, D, device="cuda", generator=g) for _ in range(3))
+    o = fastmax(q, k, v)
+    for (b, h) in ((0, 0), (7, 13), (15, 31)):
+        ro, _ = c_oracle.fwd(*(t[b:b + 1, h:h + 1].cpu().numpy() for t in (q, k, v)))
+        assert rel_err(o[b:b + 1, h:h + 1].cpu().numpy(), ro) < TOL_FWD
+    ones = fastmax(q, k, torch.ones_like(v))
+    assert float((ones - 1).abs().max()) < 1e-4
+    v2 = torch.randn(B, H, N, D, device="cuda", generator=g)
+    o2 = fastmax(q, k, v2)
+    o3 = fastmax(q, k, 0.5 * v - 2.0 * v2)
+    assert float((o3 - (0.5 * o - 2.0 * o2)).abs().max()) < 1e-4 * float(o.abs().max() + 2 * o2.abs().max())
+    t = 2049
+    q2, k2, v3 = q.clone(), k.clone(), v.clone()
+    q2[:, :, t:], k2[:, :, t:], v3[:, :, t:] = 1.5, -0.5, 3.0
+    o4 = fastmax(q2, k2, v3)
+    assert torch.equal(o4[:, :, :t], o[:, :, :t])
+    assert not torch.equal(o4[:, :, t:], o[:, :, t:])

@@ -1,7 +1,324 @@
-// placeholder: matrix-core kernel lands here
+// fastmax p=1 masked forward on the CDNA4 matrix cores (gfx950), linear in N.
+//
+// One workgroup (4 waves) walks one (b,h) head in chunks of C = 64 tokens, carrying
+//     S2 = sum_{j<chunk} k_j v_j^T   (D x D, fp32, in MFMA accumulators; a bf16 hi/lo image of it in LDS)
+//     S1 = sum v_j,  ksum = sum k_j   (fp32, exact vector-ALU sums, in LDS)
+// and computes per chunk, with q' = a*q (a = 1/nt):
+//     O^T[d][i]  = S1[d] + (S2^T q'_i)[d]                  inter-chunk   (3)
+//                + sum_{j<=i} (1 + q'_i.k_j) v_j[d]        intra-chunk   (1) S^T = K Q'^T, (2) O^T += V^T P^T
+//     g_i        = (i+1) + q'_i.ksum_prev + sum_{j<=i in chunk} q'_i.k_j
+//     S2        += K^T V                                    state update  (4)
+// which is attention_mechanisms/fastmax.py:236-241 (F) and 306-312 (g) without the (N,D,D) temporaries.
+//
+// Numerics: fp32 inputs are split into bf16 hi + bf16 lo and every product uses 3 MFMAs
+// (hi*hi + lo*hi + hi*lo, fp32 accumulate): ~2^-16 relative per product.  gfx950 has no xf32 and its
+// fp32-input MFMA runs at 1/16 of the bf16 rate, which would leave this kernel matrix-bound.
+//
+// Work split: wave w owns queries 16w..16w+15 of the chunk (all D output columns) for (1)-(3) and the
+// value-column slab 16w..16w+15 of S2 for (4).  All operands are MFMA 16x16x32 bf16 fragments:
+//   * Q', K row reads (ds_read_b128) from row-major [token][m] images,
+//   * V^T, K^T transposed reads (ds_read_b64_tr_b16) from the same row-major images,
+//   * P^T and S2 come straight from accumulator registers (k order permuted to match, see kperm()).
+// LDS images use 128-byte rows with the 16-byte chunk index XOR-ed with (row & 7): conflict-free for
+// both kinds of read.
 #include "fastmax_common.h"
+
 namespace fastmax {
-bool mfma_p1_supported(const fastmax_problem&) { return false; }
-size_t mfma_p1_workspace(const fastmax_problem&) { return 0; }
-int launch_fwd_mfma_p1(const FwdArgs&) { return FASTMAX_E_BAD_SHAPE; }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MfmaParams {
+    const void *q, *k, *v;
+    Strides3 qs, ks, vs;
+    float* o;
+    float* g;
+    int H, N;
+    float a;
+};
+
+namespace m64 {
+constexpr int D = 64, C = 64, NT = 256;
+constexpr int IMG = C * D * 2;               // one bf16 image: 8 KiB
+constexpr int QH = 0, QL = IMG, KH = 2 * IMG, KL = 3 * IMG, VH = 4 * IMG, VL = 5 * IMG;
+constexpr int S2H = 6 * IMG, S2L = 7 * IMG;  // [d][m] images of S2^T
+constexpr int S1V = 8 * IMG;                 // 2 x 64 floats (double-buffered by chunk parity)
+constexpr int KSUM = S1V + 512;              // 2 x 64 floats
+constexpr int PARTV = KSUM + 512;            // 16 x 64 floats: per-row-group column sums of V
+constexpr int PARTK = PARTV + 4096;
+constexpr int QK = PARTK + 4096;             // 64 floats: q'_i . ksum_prev
+constexpr int LDS_BYTES = QK + 256;          // 75008
+}  // namespace m64
+
+// byte offset of 16-byte chunk `chunk` of row `row` in a swizzled 128-byte-row image
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + (((chunk ^ row) & 7) << 4); }
+
+__device__ __forceinline__ void split4(const f32x4 x, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)x[i];
+        lo[i] = (__bf16)(x[i] - (float)hi[i]);
+    }
 }
+
+__device__ __forceinline__ bf16x8 ld_row8(const char* smem, int base, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(smem + base + img_off(row, chunk));
+}
+
+// Transposed fragment: lane (r = lane&15, q = lane>>4) receives, for column `col0 + r` of the image,
+// the 8 rows  row0 + 4q + {0..3}  and  row0 + 16 + 4q + {0..3}  (the permuted k order that matches an
+// accumulator tile pair used as the other operand).  Address lanes: lane 4q'+p' of a 16-lane group
+// supplies row q' of the 4-row block, columns 4p'..4p'+3.
+__device__ __forceinline__ bf16x8 ld_tr8(const char* smem, int base, int row0, int col0, int lane) {
+    const int q = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int ra = row0 + 4 * q + qq, rb = ra + 16;
+    const int chunk = (col0 >> 3) + (pp >> 1), half = (pp & 1) << 3;
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(ra, chunk) + half));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(rb, chunk) + half));
+    return u.v;
+}
+
+// D = A.B + C, three-term split product (A = Ah + Al, B = Bh + Bl; Al.Bl dropped)
+__device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return c;
+}
+
+// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
+__device__ __forceinline__ float row16_sum_to_lane15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid = B*H workgroups, block = 256 threads, dynamic LDS = m64::LDS_BYTES.  float32 I/O, D = 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams prm) {
+    using namespace m64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N;
+    const float a = prm.a;
+
+    const float* qb = reinterpret_cast<const float*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
+    const float* kb = reinterpret_cast<const float*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const float* vb = reinterpret_cast<const float*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    float* ob = prm.o + (int64_t)bh * N * D;
+    float* gb = prm.g ? prm.g + (int64_t)bh * N : nullptr;
+
+    // staging map: thread -> (row srow + 16u, float4 column scol)
+    const int srow = tid >> 4, scol = tid & 15;
+    f32x4 rq[4], rk[4], rv[4];
+    auto issue_loads = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gn = n0 + srow + 16 * u;
+            const int gc = gn < N ? gn : N - 1;                      // clamp: always a legal address
+            const f32x4 tq = *reinterpret_cast<const f32x4*>(qb + (int64_t)gc * prm.qs.sn + 4 * scol);
+            const f32x4 tk = *reinterpret_cast<const f32x4*>(kb + (int64_t)gc * prm.ks.sn + 4 * scol);
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(vb + (int64_t)gc * prm.vs.sn + 4 * scol);
+            const float keep = gn < N ? 1.0f : 0.0f;
+            rq[u] = tq * keep; rk[u] = tk * keep; rv[u] = tv * keep;
+        }
+    };
+
+    // zero the carried state: S2 images, S1V[0], KSUM[0]
+    for (int i = tid; i < (2 * IMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + S2H + 16 * i) = f32x4{0, 0, 0, 0};
+    if (tid < 64) {
+        reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
+        reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
+    }
+    f32x4 s2acc[4];                                                  // S2[16mt + 4q4 + reg][16w + r]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) s2acc[mt] = f32x4{0, 0, 0, 0};
+
+    issue_loads(0);
+    __syncthreads();
+
+    const int nchunks = (N + C - 1) / C;
+    for (int c = 0; c < nchunks; ++c) {
+        const int n0 = c * C;
+        const int cur = c & 1, nxt = cur ^ 1;
+        const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + 64 * cur;
+        const float* s1v_cur = reinterpret_cast<const float*>(smem + S1V) + 64 * cur;
+
+        // ---- (a) registers -> bf16 hi/lo images; exact fp32 side sums -----------------------------
+        {
+            const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum_cur + 4 * scol);
+            f32x4 ck = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = srow + 16 * u;
+                const int off = img_off(row, scol >> 1) + ((scol & 1) << 3);
+                bf16x4 hi, lo;
+                const f32x4 xq = rq[u] * a;
+                split4(xq, hi, lo);
+                *reinterpret_cast<bf16x4*>(smem + QH + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + QL + off) = lo;
+                float part = xq[0] * ks4[0] + xq[1] * ks4[1] + xq[2] * ks4[2] + xq[3] * ks4[3];
+                part = row16_sum_to_lane15(part);
+                if (scol == 15) reinterpret_cast<float*>(smem + QK)[row] = part;
+                split4(rk[u], hi, lo);
+                *reinterpret_cast<bf16x4*>(smem + KH + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + KL + off) = lo;
+                split4(rv[u], hi, lo);
+                *reinterpret_cast<bf16x4*>(smem + VH + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + VL + off) = lo;
+                ck += rk[u];
+                cv += rv[u];
+            }
+            *reinterpret_cast<f32x4*>(smem + PARTK + (srow * 64 + 4 * scol) * 4) = ck;
+            *reinterpret_cast<f32x4*>(smem + PARTV + (srow * 64 + 4 * scol) * 4) = cv;
+        }
+        if (c + 1 < nchunks) issue_loads(n0 + C);                   // prefetch under this chunk's compute
+        __syncthreads();                                             // B1: images + partial sums visible
+
+        // running sums for the NEXT chunk (double-buffered, so readers of `cur` are undisturbed)
+        if (tid < 128) {
+            const int col = tid & 63;
+            const float* part = reinterpret_cast<const float*>(smem + (tid < 64 ? PARTV : PARTK));
+            float* base = reinterpret_cast<float*>(smem + (tid < 64 ? S1V : KSUM));
+            float s = base[64 * cur + col];
+#pragma unroll
+            for (int g16 = 0; g16 < 16; ++g16) s += part[g16 * 64 + col];
+            base[64 * nxt + col] = s;
+        }
+
+        // ---- phase A: this wave's 16 queries --------------------------------------------------------
+        const int qi = 16 * w + r;                                   // query row inside the chunk
+        bf16x8 qh[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qh[ks] = ld_row8(smem, QH, qi, 4 * ks + q4);
+            ql[ks] = ld_row8(smem, QL, qi, 4 * ks + q4);
+        }
+        // (3) inter-chunk: O^T = S1 + S2^T Q'^T      (A = S2^T image rows d, B = Q'^T)
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[dt] = *reinterpret_cast<const f32x4*>(s1v_cur + 16 * dt + 4 * q4);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 sh = ld_row8(smem, S2H, 16 * dt + r, 4 * ks + q4);
+                const bf16x8 sl = ld_row8(smem, S2L, 16 * dt + r, 4 * ks + q4);
+                oacc[dt] = mfma3(sh, sl, qh[ks], ql[ks], oacc[dt]);
+            }
+        }
+        // (1) scores S^T[j][i] = k_j . q'_i for key tiles jt <= w; mask the diagonal tile; P = 1 + s
+        float gsum = 0.f;
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 pt[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jt = 2 * s + e;
+                f32x4 sc = {0, 0, 0, 0};
+                if (jt <= w) {                                       // wave-uniform
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 kh = ld_row8(smem, KH, 16 * jt + r, 4 * ks + q4);
+                        const bf16x8 kl = ld_row8(smem, KL, 16 * jt + r, 4 * ks + q4);
+                        sc = mfma3(kh, kl, qh[ks], ql[ks], sc);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool keep = (jt < w) || (jt == w && (4 * q4 + i) <= r);
+                    const float sv = keep ? sc[i] : 0.f;
+                    gsum += sv;
+                    pt[e][i] = keep ? 1.0f + sv : 0.f;
+                }
+            }
+            bf16x4 h0, l0, h1, l1;
+            split4(pt[0], h0, l0);
+            split4(pt[1], h1, l1);
+            ph[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            pl[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        // (2) intra-chunk: O^T += V^T P^T   (A = V^T by transposed reads, B = P^T from registers)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (2 * s <= w) {                                        // wave-uniform
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vh = ld_tr8(smem, VH, 32 * s, 16 * dt, lane);
+                    const bf16x8 vl = ld_tr8(smem, VL, 32 * s, 16 * dt, lane);
+                    oacc[dt] = mfma3(vh, vl, ph[s], pl[s], oacc[dt]);
+                }
+            }
+        }
+        // denominator: count + q'.ksum_prev + intra-chunk score sum (over the 4 k-groups of the lane's query)
+        gsum += __shfl_xor(gsum, 16, 64);
+        gsum += __shfl_xor(gsum, 32, 64);
+        const int gi = n0 + qi;
+        const float gval = (float)(gi + 1) + reinterpret_cast<const float*>(smem + QK)[qi] + gsum;
+        const float ginv = 1.0f / gval;
+        if (gi < N) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f32x4*>(ob + (int64_t)gi * D + 16 * dt + 4 * q4) = oacc[dt] * ginv;
+            if (gb && q4 == 0) gb[gi] = gval;
+        }
+
+        // ---- phase B: S2[:, 16w..16w+15] += K^T V  (A = K^T, B = V, both by transposed reads) --------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 vh = ld_tr8(smem, VH, 32 * s, 16 * w, lane);
+            const bf16x8 vl = ld_tr8(smem, VL, 32 * s, 16 * w, lane);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bf16x8 kh = ld_tr8(smem, KH, 32 * s, 16 * mt, lane);
+                const bf16x8 kl = ld_tr8(smem, KL, 32 * s, 16 * mt, lane);
+                s2acc[mt] = mfma3(kh, kl, vh, vl, s2acc[mt]);
+            }
+        }
+        __syncthreads();                                             // B2: every read of this chunk's images is done
+
+        // ---- (e) publish the new S2 as bf16 hi/lo image rows d = 16w + r (read after the next B1) ----
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                bf16x4 hi, lo;
+                split4(s2acc[mt], hi, lo);
+                const int off = img_off(16 * w + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
+                *reinterpret_cast<bf16x4*>(smem + S2H + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + S2L + off) = lo;
+            }
+        }
+    }
+}
+
+bool mfma_p1_supported(const fastmax_problem& p) {
+    return p.p == 1 && p.causal && p.D == 64 && p.in_dtype == FASTMAX_F32 && p.out_dtype == FASTMAX_F32;
+}
+size_t mfma_p1_workspace(const fastmax_problem&) { return 0; }
+
+int launch_fwd_mfma_p1(const FwdArgs& a) {
+    if (!mfma_p1_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_p1_mfma_d64_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, m64::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    MfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, reinterpret_cast<float*>(a.o), a.g, a.prob.H, a.prob.Nq, a.prob.a};
+    hipLaunchKernelGGL(fwd_p1_mfma_d64_f32_kernel, dim3(a.prob.B * a.prob.H), dim3(256), m64::LDS_BYTES, a.stream, prm);
+    return (int)hipGetLastError();
+}
+
+}  // namespace fastmax

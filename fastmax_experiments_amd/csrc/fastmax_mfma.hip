@@ -23,6 +23,8 @@
 // both kinds of read.
 #include "fastmax_common.h"
 
+#include <cstdlib>
+
 namespace fastmax {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -103,6 +105,7 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
 // ------------------------------------------------------------------------------------------------
 // grid = B*H workgroups, block = 256 threads, dynamic LDS = m64::LDS_BYTES.  float32 I/O, D = 64.
 // ------------------------------------------------------------------------------------------------
+template <int PF, int ST>
 __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams prm) {
     using namespace m64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,17 +124,25 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 
     // staging map: thread -> (row srow + 16u, float4 column scol)
     const int srow = tid >> 4, scol = tid & 15;
-    f32x4 rq[4], rk[4], rv[4];
-    auto issue_loads = [&](int n0) {
+    auto issue_loads = [&](f32x4 (&rq)[4], f32x4 (&rk)[4], f32x4 (&rv)[4], int n0) {
+        if (n0 + C <= N) {                                           // full chunk (block-uniform)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int gn = n0 + srow + 16 * u;
-            const int gc = gn < N ? gn : N - 1;                      // clamp: always a legal address
-            const f32x4 tq = *reinterpret_cast<const f32x4*>(qb + (int64_t)gc * prm.qs.sn + 4 * scol);
-            const f32x4 tk = *reinterpret_cast<const f32x4*>(kb + (int64_t)gc * prm.ks.sn + 4 * scol);
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(vb + (int64_t)gc * prm.vs.sn + 4 * scol);
-            const float keep = gn < N ? 1.0f : 0.0f;
-            rq[u] = tq * keep; rk[u] = tk * keep; rv[u] = tv * keep;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t gn = n0 + srow + 16 * u;
+                rq[u] = *reinterpret_cast<const f32x4*>(qb + gn * prm.qs.sn + 4 * scol);
+                rk[u] = *reinterpret_cast<const f32x4*>(kb + gn * prm.ks.sn + 4 * scol);
+                rv[u] = *reinterpret_cast<const f32x4*>(vb + gn * prm.vs.sn + 4 * scol);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gn = n0 + srow + 16 * u;
+                const int gc = gn < N ? gn : N - 1;                  // clamp: always a legal address
+                const float keep = gn < N ? 1.0f : 0.0f;
+                rq[u] = *reinterpret_cast<const f32x4*>(qb + (int64_t)gc * prm.qs.sn + 4 * scol) * keep;
+                rk[u] = *reinterpret_cast<const f32x4*>(kb + (int64_t)gc * prm.ks.sn + 4 * scol) * keep;
+                rv[u] = *reinterpret_cast<const f32x4*>(vb + (int64_t)gc * prm.vs.sn + 4 * scol) * keep;
+            }
         }
     };
 
@@ -145,11 +156,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) s2acc[mt] = f32x4{0, 0, 0, 0};
 
-    issue_loads(0);
-    __syncthreads();
-
     const int nchunks = (N + C - 1) / C;
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk_body = [&](f32x4 (&rq)[4], f32x4 (&rk)[4], f32x4 (&rv)[4], int c) {
         const int n0 = c * C;
         const int cur = c & 1, nxt = cur ^ 1;
         const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + 64 * cur;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             *reinterpret_cast<f32x4*>(smem + PARTK + (srow * 64 + 4 * scol) * 4) = ck;
             *reinterpret_cast<f32x4*>(smem + PARTV + (srow * 64 + 4 * scol) * 4) = cv;
         }
-        if (c + 1 < nchunks) issue_loads(n0 + C);                   // prefetch under this chunk's compute
+        if (c + PF < nchunks) issue_loads(rq, rk, rv, n0 + PF * C);  // refill this register set: PF chunks ahead
         __syncthreads();                                             // B1: images + partial sums visible
 
         // running sums for the NEXT chunk (double-buffered, so readers of `cur` are undisturbed)
@@ -267,12 +275,27 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
         const int gi = n0 + qi;
         const float gval = (float)(gi + 1) + reinterpret_cast<const float*>(smem + QK)[qi] + gsum;
         const float ginv = 1.0f / gval;
-        if (gi < N) {
+        if constexpr (ST == 0) {
+            if (gi < N) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<f32x4*>(ob + (int64_t)gi * D + 16 * dt + 4 * q4) = oacc[dt] * ginv;
+            }
+        } else {
+            // stage the wave's 16 x 64 fp32 tile through its own (already consumed) Q'-image rows so that
+            // every store instruction writes 4 whole 256-byte rows: cols 0..31 -> QH rows, 32..63 -> QL rows
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<f32x4*>(ob + (int64_t)gi * D + 16 * dt + 4 * q4) = oacc[dt] * ginv;
-            if (gb && q4 == 0) gb[gi] = gval;
+                *reinterpret_cast<f32x4*>(smem + ((dt >> 1) ? QL : QH) + img_off(qi, (dt & 1) * 4 + q4)) = oacc[dt] * ginv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rl = 4 * u + q4, c16 = r;                 // row inside the wave tile, 16-byte column
+                const f32x4 val = *reinterpret_cast<const f32x4*>(smem + ((c16 >> 3) ? QL : QH) + img_off(16 * w + rl, c16 & 7));
+                const int go = n0 + 16 * w + rl;
+                if (go < N) *reinterpret_cast<f32x4*>(ob + (int64_t)go * D + 4 * c16) = val;
+            }
         }
+        if (gi < N && gb && q4 == 0) gb[gi] = gval;
 
         // ---- phase B: S2[:, 16w..16w+15] += K^T V  (A = K^T, B = V, both by transposed reads) --------
 #pragma unroll
@@ -299,6 +322,22 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
                 *reinterpret_cast<bf16x4*>(smem + S2L + off) = lo;
             }
         }
+    };
+
+    f32x4 aq[4], ak[4], av[4];
+    if constexpr (PF == 1) {
+        issue_loads(aq, ak, av, 0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) chunk_body(aq, ak, av, c);
+    } else {
+        f32x4 bq[4], bk[4], bv[4];
+        issue_loads(aq, ak, av, 0);
+        if (nchunks > 1) issue_loads(bq, bk, bv, C);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk_body(aq, ak, av, c);
+            if (c + 1 < nchunks) chunk_body(bq, bk, bv, c + 1);
+        }
     }
 }
 
@@ -307,18 +346,33 @@ bool mfma_p1_supported(const fastmax_problem& p) {
 }
 size_t mfma_p1_workspace(const fastmax_problem&) { return 0; }
 
-int launch_fwd_mfma_p1(const FwdArgs& a) {
-    if (!mfma_p1_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+template <int PF, int ST>
+static int launch_variant(const MfmaParams& prm, int nblocks, hipStream_t stream) {
     static bool attr_set = false;
+    auto kern = fwd_p1_mfma_d64_f32_kernel<PF, ST>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_p1_mfma_d64_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, m64::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           m64::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    MfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, reinterpret_cast<float*>(a.o), a.g, a.prob.H, a.prob.Nq, a.prob.a};
-    hipLaunchKernelGGL(fwd_p1_mfma_d64_f32_kernel, dim3(a.prob.B * a.prob.H), dim3(256), m64::LDS_BYTES, a.stream, prm);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), m64::LDS_BYTES, stream, prm);
     return (int)hipGetLastError();
+}
+
+int launch_fwd_mfma_p1(const FwdArgs& a) {
+    if (!mfma_p1_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    // FASTMAX_MFMA_VARIANT = <prefetch distance 1|2><staged stores 0|1>, tuning knob for A/B runs
+    const char* env = getenv("FASTMAX_MFMA_VARIANT");
+    const int variant = env ? atoi(env) : 11;
+    MfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, reinterpret_cast<float*>(a.o), a.g, a.prob.H, a.prob.Nq, a.prob.a};
+    const int nb = a.prob.B * a.prob.H;
+    switch (variant) {
+        case 10: return launch_variant<1, 0>(prm, nb, a.stream);
+        case 20: return launch_variant<2, 0>(prm, nb, a.stream);
+        case 21: return launch_variant<2, 1>(prm, nb, a.stream);
+        default: return launch_variant<1, 1>(prm, nb, a.stream);
+    }
 }
 
 }  // namespace fastmax

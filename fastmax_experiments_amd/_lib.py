@@ -17,7 +17,8 @@ E_BAD_P = -1
 # every symbol include/fastmax_hip.h declares
 SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_backward_workspace",
            "fastmax_hip_backward", "fastmax_hip_normalize_workspace", "fastmax_hip_normalize",
-           "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string"]
+           "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string",
+           "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
 
 
 class Problem(ctypes.Structure):
@@ -56,6 +57,13 @@ def lib():
     L.fastmax_hip_normalize_workspace.restype = sz
     L.fastmax_hip_normalize.argtypes = [vp, i64p, ci, fp, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize.restype = ci
+    i64 = ctypes.c_int64
+    L.fastmax_hip_nf4_linear_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp]
+    L.fastmax_hip_nf4_linear_forward.restype = ci
+    L.fastmax_hip_nf4_linear_backward_input.argtypes = [vp, i64, vp, vp, vp, i64, ci, ci, ci, ci, vp]
+    L.fastmax_hip_nf4_linear_backward_input.restype = ci
+    L.fastmax_hip_nf4_dequantize.argtypes = [vp, vp, vp, i64, ci, vp]
+    L.fastmax_hip_nf4_dequantize.restype = ci
     L.fastmax_hip_abi_version.restype = ci
     L.fastmax_hip_select_path.argtypes = [pp]
     L.fastmax_hip_select_path.restype = ci

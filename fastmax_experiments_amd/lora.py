@@ -1,0 +1,348 @@
+"""QLoRA linear layers for MI355X: NF4 base weight + LoRA branch, fused in one HIP kernel.
+
+Mirrors the reference's ``lit_gpt/lora.py`` interface for the two layers on the fastmax path:
+  LoRALinear       lora.py:88-177   (ctor args, lora_A/lora_B/scaling, get_lora_AB 137-139, merge 142-168, forward 170-177)
+  LoRAQKVLinear    lora.py:180-433  (lora_ind 263-278, zero_pad 281-342, conv1d 344-377, get_lora_AB 379-389, forward 398-433)
+and the quantised base layer the reference gets by monkey-patching ``torch.nn.Linear`` with bitsandbytes'
+``Linear4bit`` under Lightning's BitsandbytesPrecision plugin (finetune/lora.py:72-78): here ``NF4Linear``
+(packed uint8 ``weight`` + ``weight.quant_state``; consumers' touch points: lora.py:151-161, utils.py:36-38).
+
+bitsandbytes is not in the reference tree and not installed: the NF4 format follows the public definition
+(QLoRA, arXiv 2305.14314) -- 16-level normal-float codebook, block size 64, fp32 absmax per block, two codes
+per byte with the first element in the high nibble.  Parity with bitsandbytes' own kernels is UNPINNED.
+
+Fused forward (csrc/nf4_lora.hip):  y = x deq(W)^T + bias + (dropout(x) A^T) (scaling * scatter(B))^T
+"""
+import ctypes
+import math
+from typing import Any, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+NF4_CODE = torch.tensor([-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453,
+                         -0.28444138169288635, -0.18477343022823334, -0.09105003625154495, 0.0,
+                         0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+                         0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0], dtype=torch.float32)
+BLOCK = 64
+RANK_PAD = 32          # the fused kernel carries the LoRA branch as one 32-wide k-step
+
+
+# ---------------------------------------------------------------------------------------------
+# NF4 codec (host / device tensor ops; quantisation happens once at load time, not on the hot path)
+# ---------------------------------------------------------------------------------------------
+def nf4_quantize(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(out,in) float weight -> (packed uint8 [out*in/2], absmax float32 [out*in/64])."""
+    if w.numel() % BLOCK:
+        raise ValueError(f"NF4 needs a multiple of {BLOCK} weights, got {w.numel()}")
+    flat = w.detach().float().reshape(-1, BLOCK)
+    absmax = flat.abs().amax(dim=1)
+    scaled = flat / absmax.clamp_min(1e-38)[:, None]
+    code = NF4_CODE.to(w.device)
+    idx = (scaled[..., None] - code).abs().argmin(dim=-1).to(torch.uint8).reshape(-1)
+    packed = (idx[0::2] << 4) | idx[1::2]
+    return packed.contiguous(), absmax.contiguous()
+
+
+def nf4_dequantize(packed: torch.Tensor, absmax: torch.Tensor, shape, dtype=torch.float32) -> torch.Tensor:
+    """Inverse of nf4_quantize (HIP kernel for device tensors, tensor ops for host tensors)."""
+    n = int(torch.Size(shape).numel())
+    if packed.device.type == "cuda" and dtype in (torch.float32, torch.bfloat16):
+        out = torch.empty(n, dtype=dtype, device=packed.device)
+        with torch.cuda.device(packed.device):
+            rc = _lib.lib().fastmax_hip_nf4_dequantize(packed.data_ptr(), absmax.data_ptr(), out.data_ptr(), n,
+                                                       _lib.F32 if dtype == torch.float32 else _lib.BF16,
+                                                       ctypes.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream))
+        _lib.check(rc, "fastmax_hip_nf4_dequantize")
+        return out.view(shape)
+    code = NF4_CODE.to(packed.device)
+    idx = torch.stack([packed >> 4, packed & 15], dim=1).reshape(-1).long()
+    vals = code[idx].reshape(-1, BLOCK) * absmax[:, None]
+    return vals.reshape(shape).to(dtype)
+
+
+class Params4bit(nn.Parameter):
+    """Packed NF4 storage that looks like what lora.py:151-161 / utils.py:36-38 touch on a bnb weight:
+    ``dtype == torch.uint8`` and ``quant_state`` with the original shape at index 1."""
+
+    def __new__(cls, data, quant_state=None):
+        self = torch.Tensor._make_subclass(cls, data, False)
+        self.quant_state = quant_state
+        return self
+
+
+class NF4Linear(nn.Module):
+    """``torch.nn.Linear``-compatible frozen layer with a 4-bit NF4 weight (forward in compute dtype)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        n = in_features * out_features
+        self.weight = Params4bit(torch.zeros(n // 2, dtype=torch.uint8, device=device),
+                                 [torch.ones(n // BLOCK, dtype=torch.float32, device=device),
+                                  torch.Size((out_features, in_features)), dtype or torch.bfloat16, BLOCK, None, "nf4"])
+        self.bias = nn.Parameter(torch.zeros(out_features, dtype=torch.float32, device=device),
+                                 requires_grad=False) if bias else None
+
+    @classmethod
+    def from_linear(cls, lin: nn.Linear) -> "NF4Linear":
+        q = cls(lin.in_features, lin.out_features, bias=lin.bias is not None, device=lin.weight.device,
+                dtype=lin.weight.dtype)
+        q.load_dense(lin.weight.data, None if lin.bias is None else lin.bias.data)
+        return q
+
+    def load_dense(self, w: torch.Tensor, bias=None):
+        packed, absmax = nf4_quantize(w)
+        qs = [absmax, torch.Size(w.shape), w.dtype, BLOCK, None, "nf4"]
+        self.weight = Params4bit(packed, qs)
+        if bias is not None:
+            self.bias = nn.Parameter(bias.detach().float().clone(), requires_grad=False)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        qs = self.weight.quant_state
+        moved = fn(qs[0])
+        qs[0] = moved if moved.dtype == torch.float32 else qs[0].to(moved.device)       # absmax stays fp32
+        if self.weight.dtype != torch.uint8:                                              # .to(dtype) must not touch codes
+            raise RuntimeError("NF4 codes were cast; move NF4Linear with .to(device) only")
+        self.weight.quant_state = qs
+        return self
+
+    def dequantize(self, dtype=torch.float32) -> torch.Tensor:
+        return nf4_dequantize(self.weight.data, self.weight.quant_state[0], self.weight.quant_state[1], dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return qlora_linear(x, self, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused op
+# ---------------------------------------------------------------------------------------------
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _QLoRALinearFn(torch.autograd.Function):
+    """y = x deq(W)^T + bias + ea eb^T, all in one HIP kernel; dx through the dequant GEMM,
+    d(ea), d(eb) are thin library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x2, ea, eb, wq, absmax, bias, N, K):
+        M = x2.shape[0]
+        dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
+        y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+        with torch.cuda.device(x2.device):
+            rc = _lib.lib().fastmax_hip_nf4_linear_forward(
+                x2.data_ptr(), x2.stride(0), wq.data_ptr(), absmax.data_ptr(),
+                None if bias is None else bias.data_ptr(), None if ea is None else ea.data_ptr(),
+                None if eb is None else eb.data_ptr(), y.data_ptr(), N, M, N, K, dt, _stream(x2.device))
+        _lib.check(rc, "fastmax_hip_nf4_linear_forward")
+        ctx.save_for_backward(ea, eb, wq, absmax)
+        ctx.dims = (M, N, K, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ea, eb, wq, absmax = ctx.saved_tensors
+        M, N, K, dt = ctx.dims
+        dy = dy.contiguous()
+        dx = d_ea = d_eb = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+            with torch.cuda.device(dy.device):
+                rc = _lib.lib().fastmax_hip_nf4_linear_backward_input(dy.data_ptr(), N, wq.data_ptr(), absmax.data_ptr(),
+                                                                      dx.data_ptr(), K, M, N, K, dt, _stream(dy.device))
+            _lib.check(rc, "fastmax_hip_nf4_linear_backward_input")
+        if ea is not None:
+            dyb = dy.to(torch.bfloat16)
+            if ctx.needs_input_grad[1]:
+                d_ea = dyb @ eb                       # (M,N)(N,32): thin GEMM, library call
+            if ctx.needs_input_grad[2]:
+                d_eb = dyb.t() @ ea                   # (N,M)(M,32)
+        return dx, d_ea, d_eb, None, None, None, None, None
+
+
+def qlora_linear(x, base: NF4Linear, ea, eb):
+    """x: (..., K) device tensor (bf16 or f32). ea: (M, r_tot) or None, eb: (N, r_tot) or None."""
+    if x.device.type != "cuda":
+        raise RuntimeError("the NF4 + LoRA linear runs on an MI355X only; there is no CPU fallback")
+    N, K = base.out_features, base.in_features
+    if K % 128 or N % 64:
+        raise NotImplementedError(f"fused NF4 linear needs in_features % 128 == 0 and out_features % 64 == 0, got {K}, {N}")
+    cdt = x.dtype if x.dtype in (torch.bfloat16, torch.float32) else torch.bfloat16
+    x2 = x.reshape(-1, K).to(cdt)
+    if x2.stride(1) != 1 or (x2.stride(0) * x2.element_size()) % 16 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    if ea is not None:
+        r = ea.shape[-1]
+        ea = F.pad(ea.reshape(-1, r).to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
+        eb = F.pad(eb.to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
+    bias = None if base.bias is None else base.bias.data
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, base.weight.quant_state[0], bias, N, K)
+    return y.reshape(*x.shape[:-1], N).to(x.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# LoRA layers (reference interface)
+# ---------------------------------------------------------------------------------------------
+class LoRALayer(nn.Module):
+    def __init__(self, r: int, lora_alpha: int, lora_dropout: float):
+        super().__init__()
+        assert r >= 0
+        self.r, self.lora_alpha = r, lora_alpha
+        self.lora_dropout = nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else (lambda x: x)
+        self.merged = False
+
+
+class LoRALinear(LoRALayer):
+    """lit_gpt/lora.py:88-177."""
+
+    def __init__(self, in_features: int, out_features: int, r: int = 0, lora_alpha: int = 1, lora_dropout: float = 0.0,
+                 **kwargs: Any):
+        super().__init__(r=r, lora_alpha=lora_alpha, lora_dropout=lora_dropout)
+        self.linear = torch.nn.Linear(in_features, out_features, **kwargs)
+        if r > 0:
+            self.lora_A = nn.Parameter(torch.zeros((r, in_features)))
+            self.lora_B = nn.Parameter(torch.zeros((out_features, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        if hasattr(self, "lora_A"):
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+            nn.init.zeros_(self.lora_B)
+
+    def quantize_base(self) -> "LoRALinear":
+        """Swap the dense frozen layer for its NF4 version (what the bnb plugin does at construction)."""
+        if not isinstance(self.linear, NF4Linear):
+            self.linear = NF4Linear.from_linear(self.linear)
+        return self
+
+    def get_lora_AB(self) -> torch.Tensor:
+        return (self.lora_B @ self.lora_A) * self.scaling
+
+    def _dense_rows(self) -> torch.Tensor:
+        """(out_features, r_total) matrix E with  lora(x) = (dropout(x) A^T) E^T * scaling."""
+        return self.lora_B
+
+    def merge(self) -> None:
+        """W <- W + dW (lora.py:142-168); the 4-bit branch dequantises, adds and requantises."""
+        if self.r > 0 and not self.merged:
+            lora_data = self.get_lora_AB()
+            if isinstance(self.linear, NF4Linear):
+                w = self.linear.dequantize(torch.float32) + lora_data.float().to(self.linear.weight.device)
+                self.linear.load_dense(w.to(self.linear.weight.quant_state[2]))
+            elif self.linear.weight.data.dtype == lora_data.dtype:
+                self.linear.weight.data += lora_data
+            else:
+                raise NotImplementedError(f"Cannot merge the pretrained weights of type {self.linear.weight.data.dtype}"
+                                          f" and LoRA weights of type {lora_data.dtype}")
+            self.merged = True
+
+    def _lora_enabled(self) -> bool:
+        return self.r > 0 and not self.merged
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self._lora_enabled():
+            return self.linear(x)
+        if isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD:
+            ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
+            return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
+        pretrained = self.linear(x)
+        lora = (self.lora_dropout(x) @ self.lora_A.transpose(0, 1).to(x.dtype)) @ self._dense_rows().transpose(0, 1).to(x.dtype)
+        return pretrained + lora * self.scaling
+
+
+class LoRAQKVLinear(LoRALinear):
+    """lit_gpt/lora.py:180-433: LoRA on the fused, GQA-interleaved QKV projection."""
+
+    def __init__(self, in_features: int, out_features: int, n_head: int, n_query_groups: int, r: int = 0,
+                 lora_alpha: int = 1, lora_dropout: float = 0.0,
+                 enable_lora: Union[bool, Tuple[bool, bool, bool]] = False, **kwargs: Any):
+        super(LoRALinear, self).__init__(r=r, lora_alpha=lora_alpha, lora_dropout=lora_dropout)
+        self.linear = torch.nn.Linear(in_features, out_features, **kwargs)
+        self.n_head, self.n_query_groups = n_head, n_query_groups
+        if isinstance(enable_lora, bool):
+            enable_lora = [enable_lora] * 3
+        assert len(enable_lora) == 3
+        self.enable_lora = enable_lora
+        if r > 0 and any(enable_lora):
+            self.lora_A = nn.Parameter(torch.zeros((r * sum(enable_lora), in_features)))
+            enable_q, enable_k, enable_v = enable_lora
+            self.kv_embd_size = self.linear.in_features // (n_head // n_query_groups)
+            qkv_shapes = (self.linear.in_features * enable_q, self.kv_embd_size * enable_k, self.kv_embd_size * enable_v)
+            self.qkv_shapes = [s for s in qkv_shapes if s]
+            self.lora_B = nn.Parameter(torch.zeros(sum(self.qkv_shapes), r))
+            self.scaling = self.lora_alpha / self.r
+            # which output columns each enabled part owns in the interleaved [Q..Q K V | Q..Q K V | ...] layout
+            q_per_kv = self.n_head // self.n_query_groups
+            total_qkv = q_per_kv + 2
+            head_size = out_features // (self.n_query_groups * total_qkv)
+            ind = range(out_features)
+            self.lora_ind = []
+            if enable_q:
+                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv < total_qkv - 2)
+            if enable_k:
+                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv == total_qkv - 2)
+            if enable_v:
+                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv == total_qkv - 1)
+            # column block (0..n_enabled-1) of every lora_B row: rows are ordered part by part
+            part = torch.repeat_interleave(torch.arange(len(self.qkv_shapes)), torch.tensor(self.qkv_shapes))
+            self.register_buffer("_ind", torch.tensor(self.lora_ind, dtype=torch.long), persistent=False)
+            self.register_buffer("_cols", part[:, None] * r + torch.arange(r)[None, :], persistent=False)
+            self.reset_parameters()
+
+    def zero_pad(self, x: torch.Tensor) -> torch.Tensor:
+        """Scatter the enabled parts' columns into the full interleaved QKV width (lora.py:281-342)."""
+        if all(self.enable_lora):
+            return x
+        x = x.transpose(0, 1)
+        result = x.new_zeros((*x.shape[:-1], self.linear.out_features))
+        result = result.view(-1, self.linear.out_features)
+        result = result.index_copy(1, self._ind.to(result.device), x.reshape(-1, sum(self.qkv_shapes)))
+        return result.view((*x.shape[:-1], self.linear.out_features)).transpose(0, 1)
+
+    def conv1d(self, input: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """Grouped 1x1 convolution == block-diagonal matmul over the enabled parts (lora.py:344-377)."""
+        if self.n_head == self.n_query_groups:
+            return F.conv1d(input, weight, groups=sum(self.enable_lora))
+        input_splitted = input.chunk(sum(self.enable_lora), dim=1)
+        weight_splitted = weight.split(self.qkv_shapes)
+        return torch.cat([F.conv1d(a, b) for a, b in zip(input_splitted, weight_splitted)], dim=1)
+
+    def get_lora_AB(self) -> torch.Tensor:
+        lora = self.conv1d(self.lora_A.data.unsqueeze(0), self.lora_B.data.unsqueeze(-1)).squeeze(0)
+        return self.zero_pad(lora * self.scaling)
+
+    def _dense_rows(self) -> torch.Tensor:
+        """(out_features, r*n_enabled): lora_B scattered to its output columns and rank block, zeros elsewhere,
+        so that zero_pad(conv1d(after_A, B)) == after_A @ E^T   (lora.py:426-432 as one small dense operand)."""
+        E = self.lora_B.new_zeros((self.linear.out_features, self.lora_A.shape[0]))
+        # zero_pad is the identity when all three parts are enabled (lora.py:317-318): the rows then sit at
+        # their own index, NOT at lora_ind -- kept as the reference has it
+        ind = torch.arange(self.linear.out_features, device=E.device) if all(self.enable_lora) else self._ind.to(E.device)
+        rows = ind[:, None].expand(-1, self.r)
+        return E.index_put((rows, self._cols.to(E.device)), self.lora_B)
+
+    def merge(self) -> None:
+        if self.r > 0 and any(self.enable_lora) and not self.merged:
+            super().merge()
+
+    def _lora_enabled(self) -> bool:
+        return self.r > 0 and any(self.enable_lora) and not self.merged
+
+
+def mark_only_lora_as_trainable(model: nn.Module) -> None:
+    """lit_gpt/lora.py:450-452."""
+    for n, p in model.named_parameters():
+        p.requires_grad = "lora_" in n
+
+
+def lora_filter(key: str, value: Any) -> bool:
+    """lit_gpt/lora.py:469-470."""
+    return "lora_" in key

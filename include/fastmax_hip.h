@@ -56,7 +56,7 @@ enum fastmax_path {
 typedef struct fastmax_problem {
     int B, H, Nq, Nk, D;
     int in_dtype;    /* enum fastmax_dtype of q,k,v (and grad_o)                       */
-    int out_dtype;   /* enum fastmax_dtype of o (and dq,dk,dv); see dtype rule Q1       */
+    int out_dtype;   /* enum fastmax_dtype of o; see dtype rule Q1 (grads use in_dtype) */
     int p;           /* 1 or 2: degree of the Taylor polynomial f                       */
     int causal;      /* 1 = `mask=True` of the reference (j <= i), needs Nq == Nk       */
     float a;         /* 1/nt          (nt: fastmax.py:78-82)                            */
@@ -103,6 +103,27 @@ size_t fastmax_hip_normalize_workspace(int B, int H);
 int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype,
                           float* y, float* inv_norm, int B, int H, int N, int D,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- QLoRA linear: frozen NF4 base weight + LoRA branch, fused (csrc/nf4_lora.hip).
+ *      Replaces the bitsandbytes Linear4bit matmul + the low-rank branch of
+ *      lit_gpt/lora.py:170-177 (LoRALinear.forward) and :398-433 (LoRAQKVLinear.forward):
+ *        y[M][N] = x[M][K] . deq(W)[N][K]^T + bias[N] + ea[M][32] . eb[N][32]^T
+ *      wq: packed NF4 codes of the row-major (N,K) weight, two per byte, high nibble first;
+ *      absmax: float32, one per 64 consecutive weights (block size 64); bias: float32 or NULL.
+ *      ea = dropout(x) A^T and eb = scaling * scatter(lora_B) are bf16, rank padded to 32 columns
+ *      (both NULL = no LoRA branch).  x, y: `dtype` (FASTMAX_BF16 or FASTMAX_F32), leading
+ *      dimensions in elements.  Needs K % 64 == 0, N % 4 == 0, 16-byte aligned rows.
+ *      NF4 follows the public QLoRA definition; parity with bitsandbytes is unpinned.           */
+int fastmax_hip_nf4_linear_forward(const void* x, int64_t ldx, const uint8_t* wq, const float* absmax,
+                                   const float* bias, const void* ea, const void* eb, void* y, int64_t ldy,
+                                   int M, int N, int K, int dtype, void* stream);
+/*      dx[M][K] = dy[M][N] . deq(W)[N][K]  (gradient wrt the input of the frozen base layer).
+ *      Needs K % 128 == 0, N % 64 == 0.                                                         */
+int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const uint8_t* wq, const float* absmax,
+                                          void* dx, int64_t lddx, int M, int N, int K, int dtype, void* stream);
+/*      dense dequantisation (merge path: lora.py:142-168 dequantize + add LoRA + requantize)     */
+int fastmax_hip_nf4_dequantize(const uint8_t* wq, const float* absmax, void* out, int64_t n, int dtype,
+                               void* stream);
 
 /* ---- introspection */
 int fastmax_hip_abi_version(void);

@@ -20,7 +20,7 @@ def lib():
 
 def test_header_symbols_all_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "fastmax_hip.h")).read()
-    declared = set(re.findall(r"\b(fastmax_hip_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(fastmax_hip_[a-z0-9_]+)\s*\(", hdr))
     from fastmax_experiments_amd import _lib
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:

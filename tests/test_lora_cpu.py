@@ -1,0 +1,131 @@
+"""Host logic of the QLoRA layers, pinned by the data the reference's own tests hold for lit_gpt/lora.py
+(tests/test_lora.py:83-159 lora_ind / zero_pad / non-zero columns, :333-369 conv1d equivalence, :37-80 merge),
+plus the NF4 codec's self-consistency (bitsandbytes is absent: NF4 values are 'parity unpinned')."""
+import pytest
+import torch
+from torch.nn import functional as F
+
+from fastmax_experiments_amd import lora
+
+
+def _qkv(n_head, n_query_groups, n_embd=8, r=2, enable=(True, False, True)):
+    hs = n_embd // n_head
+    return lora.LoRAQKVLinear(n_embd, (n_head + 2 * n_query_groups) * hs, n_head=n_head, n_query_groups=n_query_groups,
+                              r=r, lora_alpha=8, lora_dropout=0.1, enable_lora=enable)
+
+
+@pytest.mark.parametrize("groups,out,ind,bshape", [
+    (4, 24, [0, 1, 6, 7, 12, 13, 18, 19, 4, 5, 10, 11, 16, 17, 22, 23], (16, 2)),      # MHA
+    (1, 12, [0, 1, 2, 3, 4, 5, 6, 7, 10, 11], (10, 2)),                                # MQA
+    (2, 16, [0, 1, 2, 3, 8, 9, 10, 11, 6, 7, 14, 15], (12, 2)),                        # GQA
+])
+def test_lora_mqa_gqa_pins(groups, out, ind, bshape):
+    attn = _qkv(4, groups)
+    for p in attn.linear.parameters():
+        torch.nn.init.zeros_(p)
+    torch.nn.init.ones_(attn.lora_B)
+    assert attn.linear.weight.shape == (out, 8)
+    assert attn.lora_A.shape == (4, 8) and attn.lora_B.shape == bshape
+    assert attn.lora_ind == ind
+    x = torch.randint(0, 8, size=(3, 5, len(ind)), dtype=torch.int64)
+    assert attn.zero_pad(x).shape == (3, 5, out)
+    attn.eval()
+    y = attn(torch.randn(2, 30, 8))
+    non = list(set(range(out)).difference(ind))
+    assert torch.count_nonzero(y[:, :, ind]) == 2 * 30 * len(ind)
+    assert torch.count_nonzero(y[:, :, non]) == 0
+
+
+@torch.inference_mode()
+@pytest.mark.parametrize("n_head", (1, 2, 3, 6, 12))
+@pytest.mark.parametrize("enable_lora", [(False, False, True), (False, True, False), (False, True, True),
+                                         (True, False, False), (True, False, True), (True, True, False),
+                                         (True, True, True)])
+def test_conv1d_equivalence_and_dense_operand(n_head, enable_lora):
+    C = 12
+    layer = lora.LoRAQKVLinear(C, 3 * C, n_head=n_head, n_query_groups=n_head, r=2, enable_lora=enable_lora)
+    torch.nn.init.normal_(layer.lora_B)
+    x = torch.randn((1, 1, C))
+    a = F.linear(x, layer.lora_A).transpose(-2, -1)
+    b = layer.lora_B.data.unsqueeze(-1)
+    ref = F.conv1d(a, b, groups=sum(layer.enable_lora))
+    assert torch.allclose(ref, layer.conv1d(a, b))
+    layer.n_head = layer.n_query_groups + 1
+    assert torch.allclose(ref, layer.conv1d(a, b))
+    # the single dense operand the fused kernel consumes reproduces zero_pad(conv1d(.)) exactly
+    after_A = F.linear(x, layer.lora_A)
+    want = layer.zero_pad(layer.conv1d(after_A.transpose(-2, -1), b).transpose(-2, -1))
+    got = after_A @ layer._dense_rows().T
+    assert torch.allclose(want, got, atol=1e-6)
+
+
+@pytest.mark.parametrize("groups", [4, 2, 1])
+def test_dense_operand_gqa(groups):
+    layer = _qkv(4, groups, n_embd=16, r=3, enable=(True, True, True) if groups == 2 else (True, False, True))
+    torch.nn.init.normal_(layer.lora_B)
+    x = torch.randn(2, 7, 16)
+    after_A = F.linear(x, layer.lora_A)
+    want = layer.zero_pad(layer.conv1d(after_A.transpose(-2, -1), layer.lora_B.unsqueeze(-1)).transpose(-2, -1))
+    assert torch.allclose(want, after_A @ layer._dense_rows().T, atol=1e-6)
+    assert torch.allclose(layer.get_lora_AB(), layer._dense_rows() @ layer.lora_A * layer.scaling, atol=1e-6)
+
+
+def test_lora_merge_dense():
+    layer = lora.LoRALinear(16, 24, r=4, lora_alpha=8)
+    torch.nn.init.normal_(layer.lora_B)
+    w0 = layer.linear.weight.data.clone()
+    x = torch.randn(3, 16)
+    y0 = layer(x)
+    delta = layer.get_lora_AB()
+    layer.merge()
+    assert layer.merged and torch.allclose(layer.linear.weight.data, w0 + delta)
+    assert torch.allclose(layer(x), y0, atol=1e-5)
+    layer.merge()                                            # idempotent
+    assert torch.allclose(layer.linear.weight.data, w0 + delta)
+
+
+def test_only_lora_trainable_and_filter():
+    m = torch.nn.Sequential(lora.LoRALinear(8, 8, r=2), lora.LoRAQKVLinear(8, 24, 4, 4, r=2, enable_lora=True))
+    lora.mark_only_lora_as_trainable(m)
+    names = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert names == {"0.lora_A", "0.lora_B", "1.lora_A", "1.lora_B"}
+    assert lora.lora_filter("x.lora_A", None) and not lora.lora_filter("x.linear.weight", None)
+
+
+# ---- NF4 codec ------------------------------------------------------------------------------
+def test_nf4_codebook_and_packing():
+    code = lora.NF4_CODE
+    assert code.numel() == 16 and code[0] == -1 and code[7] == 0 and code[15] == 1 and torch.all(code[1:] > code[:-1])
+    # weights that ARE codes times an absmax round-trip exactly; first element in the high nibble
+    idx = torch.arange(64) % 16
+    w = (code[idx] * 3.0).reshape(1, 64)
+    packed, absmax = lora.nf4_quantize(w)
+    assert packed.dtype == torch.uint8 and packed.numel() == 32 and absmax.tolist() == [3.0]
+    assert packed[0].item() == (0 << 4) | 1 and packed[1].item() == (2 << 4) | 3
+    assert torch.equal(lora.nf4_dequantize(packed, absmax, (1, 64)), w)
+
+
+def test_nf4_error_bound_and_idempotence():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(96, 128, generator=g)
+    packed, absmax = lora.nf4_quantize(w)
+    assert packed.numel() == w.numel() // 2 and absmax.numel() == w.numel() // 64
+    d = lora.nf4_dequantize(packed, absmax, w.shape)
+    gap = (lora.NF4_CODE[1:] - lora.NF4_CODE[:-1]).max() / 2
+    err = (d - w).reshape(-1, 64).abs() / absmax[:, None]
+    assert float(err.max()) <= float(gap) + 1e-6
+    p2, a2 = lora.nf4_quantize(d)
+    assert torch.equal(p2, packed) and torch.allclose(a2, absmax)
+    with pytest.raises(ValueError):
+        lora.nf4_quantize(torch.zeros(3, 5))
+
+
+def test_nf4linear_looks_like_a_bnb_weight():
+    lin = torch.nn.Linear(128, 64)
+    q = lora.NF4Linear.from_linear(lin)
+    assert q.weight.dtype == torch.uint8 and q.weight.numel() == 128 * 64 // 2 and not q.weight.requires_grad
+    assert tuple(q.weight.quant_state[1]) == (64, 128)                 # utils.py:36-38 reads the shape here
+    assert q.weight.quant_state[0].dtype == torch.float32
+    assert (q.dequantize() - lin.weight.data).abs().max() < 0.2 * lin.weight.data.abs().max()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        q(torch.randn(2, 128))

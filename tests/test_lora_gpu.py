@@ -1,0 +1,133 @@
+"""NF4 + LoRA fused linear on the MI355X: the HIP kernels (through ctypes -> C ABI) against dense tensor
+math on the SAME dequantised weights.  bitsandbytes is absent, so NF4 values are 'parity unpinned'
+(SURVEY 8c): these tests pin self-consistency -- quantise -> fused kernel == dequantise -> dense matmul."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+def test_hip_dequantize_matches_codec_bit_for_bit():
+    from fastmax_experiments_amd import lora
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(192, 256, generator=g)
+    packed, absmax = lora.nf4_quantize(w)
+    host = lora.nf4_dequantize(packed, absmax, w.shape)
+    dev = lora.nf4_dequantize(packed.cuda(), absmax.cuda(), w.shape, torch.float32)
+    assert torch.equal(dev.cpu(), host)
+    dev16 = lora.nf4_dequantize(packed.cuda(), absmax.cuda(), w.shape, torch.bfloat16)
+    assert torch.equal(dev16.cpu(), host.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (128, 128, 64), (1000, 512, 1088), (77, 2048, 2560)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_nf4_linear_forward_and_dx(M, K, N, dt):
+    from fastmax_experiments_amd import lora
+    g = torch.Generator().manual_seed(M + N)
+    lin = torch.nn.Linear(K, N)
+    torch.nn.init.normal_(lin.weight, generator=g)
+    q = lora.NF4Linear.from_linear(lin).cuda()
+    x = torch.randn(M, K, generator=g).to(dt).cuda().requires_grad_(True)
+    y = q(x)
+    assert y.shape == (M, N) and y.dtype == dt
+    wd = q.dequantize(torch.float32)
+    xr = x.detach().float().to(torch.bfloat16).float()          # the kernel feeds bf16 operands to the matrix cores
+    ref = xr @ wd.to(torch.bfloat16).float().T + q.bias.float()
+    assert _rel(y, ref) < (1.5e-2 if dt == torch.bfloat16 else 2e-5 * K ** 0.5)
+    gy = torch.randn(M, N, generator=g).to(dt).cuda()
+    y.backward(gy)
+    dref = gy.float().to(torch.bfloat16).float() @ wd.to(torch.bfloat16).float()
+    assert x.grad.dtype == dt and _rel(x.grad, dref) < (1.5e-2 if dt == torch.bfloat16 else 2e-5 * N ** 0.5)
+
+
+def _dense_reference(layer, x):
+    """lit_gpt/lora.py:419-433 with the dequantised base weight (float32 math)."""
+    from fastmax_experiments_amd import lora
+    wd = layer.linear.dequantize(torch.float32)
+    pre = x.float() @ wd.T + (0 if layer.linear.bias is None else layer.linear.bias.float())
+    after_A = F.linear(x.float(), layer.lora_A.float())
+    if isinstance(layer, lora.LoRAQKVLinear):
+        after_B = layer.conv1d(after_A.transpose(-2, -1), layer.lora_B.float().unsqueeze(-1)).transpose(-2, -1)
+        return pre + layer.zero_pad(after_B) * layer.scaling
+    return pre + after_A @ layer.lora_B.float().T * layer.scaling
+
+
+@pytest.mark.parametrize("kind", ["linear", "qkv_mha", "qkv_gqa_qv", "qkv_gqa_all"])
+def test_fused_qlora_layer_forward_backward(kind):
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(1)
+    if kind == "linear":
+        layer = lora.LoRALinear(256, 384, r=8, lora_alpha=16)
+    elif kind == "qkv_mha":
+        layer = lora.LoRAQKVLinear(256, 768, n_head=4, n_query_groups=4, r=8, lora_alpha=16, enable_lora=(True, False, True))
+    elif kind == "qkv_gqa_qv":      # TinyLlama-like grouping: 8 heads, 2 KV groups, head 32
+        layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16,
+                                   enable_lora=(True, False, True))
+    else:
+        layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda()
+    lora.mark_only_lora_as_trainable(layer)
+    assert layer.linear.weight.dtype == torch.uint8
+    x = torch.randn(2, 75, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    y = layer(x)
+    assert y.shape == (2, 75, layer.linear.out_features) and y.dtype == torch.bfloat16
+    ref = _dense_reference(layer, x.detach())
+    assert _rel(y, ref) < 2e-2
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    # reference gradients by autograd through the dense float32 formulation
+    xa = x.detach().float().requires_grad_(True)
+    A = layer.lora_A.detach().float().requires_grad_(True)
+    B = layer.lora_B.detach().float().requires_grad_(True)
+    shadow = type("S", (), {})()
+    wd = layer.linear.dequantize(torch.float32)
+    after_A = F.linear(xa, A)
+    if isinstance(layer, lora.LoRAQKVLinear):
+        after_B = layer.conv1d(after_A.transpose(-2, -1), B.unsqueeze(-1)).transpose(-2, -1)
+        lo = layer.zero_pad(after_B) * layer.scaling
+    else:
+        lo = after_A @ B.T * layer.scaling
+    yr = xa @ wd.T + layer.linear.bias.float() + lo
+    yr.backward(gy.float())
+    assert _rel(x.grad, xa.grad) < 3e-2
+    assert _rel(layer.lora_A.grad, A.grad) < 3e-2
+    assert _rel(layer.lora_B.grad, B.grad) < 3e-2
+    assert layer.linear.weight.grad is None
+
+
+def test_merge_into_nf4_requantises():
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(2)
+    layer = lora.LoRALinear(128, 128, r=4, lora_alpha=8)
+    torch.nn.init.normal_(layer.lora_B, std=0.2)
+    layer.quantize_base().cuda()
+    w0 = layer.linear.dequantize()
+    delta = layer.get_lora_AB().float()
+    layer.merge()
+    assert layer.merged and layer.linear.weight.dtype == torch.uint8
+    w1 = layer.linear.dequantize()
+    target = w0 + delta
+    # merged weight = NF4(w0 + delta): within one quantisation step of the target, and closer to it than w0 was
+    assert float((w1 - target).abs().max()) <= 0.16 * float(target.abs().max())
+    assert float((w1 - target).norm()) < float((w0 - target).norm())
+    x = torch.randn(5, 128, device="cuda", dtype=torch.bfloat16)
+    assert _rel(layer(x), x.float() @ w1.T + layer.linear.bias.float()) < 2e-2
+
+
+def test_rejects_unsupported_shapes_loudly():
+    from fastmax_experiments_amd import lora
+    q = lora.NF4Linear.from_linear(torch.nn.Linear(64, 64)).cuda()
+    with pytest.raises(NotImplementedError):
+        q(torch.randn(4, 64, device="cuda", dtype=torch.bfloat16))

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfastmax_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-PATH_AUTO, PATH_QUADRATIC, PATH_RECURRENT, PATH_MFMA = 0, 1, 2, 3
-PATH_NAMES = {PATH_AUTO: "auto", PATH_QUADRATIC: "quadratic", PATH_RECURRENT: "recurrent", PATH_MFMA: "mfma"}
+PATH_AUTO, PATH_QUADRATIC, PATH_RECURRENT, PATH_MFMA, PATH_QUADRATIC_MFMA = 0, 1, 2, 3, 4
+PATH_NAMES = {PATH_AUTO: "auto", PATH_QUADRATIC: "quadratic", PATH_RECURRENT: "recurrent", PATH_MFMA: "mfma", PATH_QUADRATIC_MFMA: "quadratic_mfma"}
 E_BAD_P = -1
 
 # every symbol include/fastmax_hip.h declares

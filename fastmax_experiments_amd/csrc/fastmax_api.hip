@@ -17,11 +17,12 @@ Strides3 st(const int64_t* s) { return Strides3{s[0], s[1], s[2]}; }
 
 int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_QUADRATIC) return FASTMAX_PATH_QUADRATIC;
+    if (p.path == FASTMAX_PATH_QUADRATIC_MFMA) return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_E_BAD_SHAPE;
     const bool lin = (p.p == 1 && p.causal);
     if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
     if (p.path == FASTMAX_PATH_MFMA) return (lin && mfma_p1_supported(p)) ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
     if (lin) return mfma_p1_supported(p) ? FASTMAX_PATH_MFMA : FASTMAX_PATH_RECURRENT;
-    return FASTMAX_PATH_QUADRATIC;
+    return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_PATH_QUADRATIC;
 }
 bool aligned16(const void* ptr, const int64_t* s, int dtype) {
     const int64_t es = dtype == FASTMAX_F32 ? 4 : 2;
@@ -69,12 +70,12 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
     if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides) return FASTMAX_E_NULL;
     int path = select(*prob);
     if (path < 0) return path;
-    if (path == FASTMAX_PATH_MFMA) {
+    if (path == FASTMAX_PATH_MFMA || path == FASTMAX_PATH_QUADRATIC_MFMA) {
         const bool ok = aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
                         aligned16(v, v_strides, prob->in_dtype) && !(reinterpret_cast<uintptr_t>(o) & 15);
         if (!ok) {
-            if (prob->path == FASTMAX_PATH_MFMA) return FASTMAX_E_ALIGNMENT;
-            path = FASTMAX_PATH_RECURRENT;
+            if (prob->path == path) return FASTMAX_E_ALIGNMENT;          // the caller forced this family
+            path = path == FASTMAX_PATH_MFMA ? FASTMAX_PATH_RECURRENT : FASTMAX_PATH_QUADRATIC;
         }
     }
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
@@ -82,6 +83,7 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
     switch (path) {
         case FASTMAX_PATH_MFMA: return launch_fwd_mfma_p1(a);
         case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
+        case FASTMAX_PATH_QUADRATIC_MFMA: return launch_fwd_quad_mfma(a);
         default: return launch_fwd_quadratic(a);
     }
 }
@@ -102,7 +104,13 @@ int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64
         return FASTMAX_E_NULL;
     BwdArgs a{*prob, q, k, v, o, grad_o, g, st(q_strides), st(k_strides), st(v_strides), st(go_strides), dq, dk, dv,
               workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
-    return launch_bwd_quadratic(a);
+    // matrix-core tiles unless the caller forces the vector-ALU family or the layout rules it out
+    const bool mfma_ok = prob->path != FASTMAX_PATH_QUADRATIC && quad_mfma_bwd_supported(*prob) &&
+                         aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
+                         aligned16(v, v_strides, prob->in_dtype) && aligned16(grad_o, go_strides, prob->in_dtype) &&
+                         !((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) |
+                            reinterpret_cast<uintptr_t>(dv)) & 15);
+    return mfma_ok ? launch_bwd_quad_mfma(a) : launch_bwd_quadratic(a);
 }
 
 size_t fastmax_hip_normalize_workspace(int B, int H) { return sizeof(unsigned int) * (size_t)B * H; }

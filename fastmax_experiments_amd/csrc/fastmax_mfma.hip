@@ -21,16 +21,11 @@
 //   * P^T and S2 come straight from accumulator registers (k order permuted to match, see kperm()).
 // LDS images use 128-byte rows with the 16-byte chunk index XOR-ed with (row & 7): conflict-free for
 // both kinds of read.
-#include "fastmax_common.h"
+#include "fastmax_mfma_common.h"
 
 #include <cstdlib>
 
 namespace fastmax {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MfmaParams {
     const void *q, *k, *v;
@@ -53,54 +48,6 @@ constexpr int PARTK = PARTV + 4096;
 constexpr int QK = PARTK + 4096;             // 64 floats: q'_i . ksum_prev
 constexpr int LDS_BYTES = QK + 256;          // 75008
 }  // namespace m64
-
-// byte offset of 16-byte chunk `chunk` of row `row` in a swizzled 128-byte-row image
-__device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + (((chunk ^ row) & 7) << 4); }
-
-__device__ __forceinline__ void split4(const f32x4 x, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = (__bf16)x[i];
-        lo[i] = (__bf16)(x[i] - (float)hi[i]);
-    }
-}
-
-__device__ __forceinline__ bf16x8 ld_row8(const char* smem, int base, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(smem + base + img_off(row, chunk));
-}
-
-// Transposed fragment: lane (r = lane&15, q = lane>>4) receives, for column `col0 + r` of the image,
-// the 8 rows  row0 + 4q + {0..3}  and  row0 + 16 + 4q + {0..3}  (the permuted k order that matches an
-// accumulator tile pair used as the other operand).  Address lanes: lane 4q'+p' of a 16-lane group
-// supplies row q' of the 4-row block, columns 4p'..4p'+3.
-__device__ __forceinline__ bf16x8 ld_tr8(const char* smem, int base, int row0, int col0, int lane) {
-    const int q = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-    const int ra = row0 + 4 * q + qq, rb = ra + 16;
-    const int chunk = (col0 >> 3) + (pp >> 1), half = (pp & 1) << 3;
-    union { bf16x8 v; s16x4 h[2]; } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(ra, chunk) + half));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(rb, chunk) + half));
-    return u.v;
-}
-
-// D = A.B + C, three-term split product (A = Ah + Al, B = Bh + Bl; Al.Bl dropped)
-__device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-    return c;
-}
-
-// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
-__device__ __forceinline__ float row16_sum_to_lane15(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // grid = B*H workgroups, block = 256 threads, dynamic LDS = m64::LDS_BYTES.  float32 I/O, D = 64.
@@ -170,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = srow + 16 * u;
-                const int off = img_off(row, scol >> 1) + ((scol & 1) << 3);
+                const int off = img_off<64>(row, scol >> 1) + ((scol & 1) << 3);
                 bf16x4 hi, lo;
                 const f32x4 xq = rq[u] * a;
                 split4(xq, hi, lo);
@@ -210,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
         bf16x8 qh[2], ql[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qh[ks] = ld_row8(smem, QH, qi, 4 * ks + q4);
-            ql[ks] = ld_row8(smem, QL, qi, 4 * ks + q4);
+            qh[ks] = ld_row8<64>(smem, QH, qi, 4 * ks + q4);
+            ql[ks] = ld_row8<64>(smem, QL, qi, 4 * ks + q4);
         }
         // (3) inter-chunk: O^T = S1 + S2^T Q'^T      (A = S2^T image rows d, B = Q'^T)
         f32x4 oacc[4];
@@ -220,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             oacc[dt] = *reinterpret_cast<const f32x4*>(s1v_cur + 16 * dt + 4 * q4);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 sh = ld_row8(smem, S2H, 16 * dt + r, 4 * ks + q4);
-                const bf16x8 sl = ld_row8(smem, S2L, 16 * dt + r, 4 * ks + q4);
+                const bf16x8 sh = ld_row8<64>(smem, S2H, 16 * dt + r, 4 * ks + q4);
+                const bf16x8 sl = ld_row8<64>(smem, S2L, 16 * dt + r, 4 * ks + q4);
                 oacc[dt] = mfma3(sh, sl, qh[ks], ql[ks], oacc[dt]);
             }
         }
@@ -238,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
                 if (jt <= w) {                                       // wave-uniform
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 kh = ld_row8(smem, KH, 16 * jt + r, 4 * ks + q4);
-                        const bf16x8 kl = ld_row8(smem, KL, 16 * jt + r, 4 * ks + q4);
+                        const bf16x8 kh = ld_row8<64>(smem, KH, 16 * jt + r, 4 * ks + q4);
+                        const bf16x8 kl = ld_row8<64>(smem, KL, 16 * jt + r, 4 * ks + q4);
                         sc = mfma3(kh, kl, qh[ks], ql[ks], sc);
                     }
                 }
@@ -263,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             if (2 * s <= w) {                                        // wave-uniform
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 vh = ld_tr8(smem, VH, 32 * s, 16 * dt, lane);
-                    const bf16x8 vl = ld_tr8(smem, VL, 32 * s, 16 * dt, lane);
+                    const bf16x8 vh = ld_tr8<64>(smem, VH, 32 * s, 16 * dt, lane);
+                    const bf16x8 vl = ld_tr8<64>(smem, VL, 32 * s, 16 * dt, lane);
                     oacc[dt] = mfma3(vh, vl, ph[s], pl[s], oacc[dt]);
                 }
             }
@@ -286,11 +233,11 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             // every store instruction writes 4 whole 256-byte rows: cols 0..31 -> QH rows, 32..63 -> QL rows
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<f32x4*>(smem + ((dt >> 1) ? QL : QH) + img_off(qi, (dt & 1) * 4 + q4)) = oacc[dt] * ginv;
+                *reinterpret_cast<f32x4*>(smem + ((dt >> 1) ? QL : QH) + img_off<64>(qi, (dt & 1) * 4 + q4)) = oacc[dt] * ginv;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int rl = 4 * u + q4, c16 = r;                 // row inside the wave tile, 16-byte column
-                const f32x4 val = *reinterpret_cast<const f32x4*>(smem + ((c16 >> 3) ? QL : QH) + img_off(16 * w + rl, c16 & 7));
+                const f32x4 val = *reinterpret_cast<const f32x4*>(smem + ((c16 >> 3) ? QL : QH) + img_off<64>(16 * w + rl, c16 & 7));
                 const int go = n0 + 16 * w + rl;
                 if (go < N) *reinterpret_cast<f32x4*>(ob + (int64_t)go * D + 4 * c16) = val;
             }
@@ -300,12 +247,12 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
         // ---- phase B: S2[:, 16w..16w+15] += K^T V  (A = K^T, B = V, both by transposed reads) --------
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8 vh = ld_tr8(smem, VH, 32 * s, 16 * w, lane);
-            const bf16x8 vl = ld_tr8(smem, VL, 32 * s, 16 * w, lane);
+            const bf16x8 vh = ld_tr8<64>(smem, VH, 32 * s, 16 * w, lane);
+            const bf16x8 vl = ld_tr8<64>(smem, VL, 32 * s, 16 * w, lane);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const bf16x8 kh = ld_tr8(smem, KH, 32 * s, 16 * mt, lane);
-                const bf16x8 kl = ld_tr8(smem, KL, 32 * s, 16 * mt, lane);
+                const bf16x8 kh = ld_tr8<64>(smem, KH, 32 * s, 16 * mt, lane);
+                const bf16x8 kl = ld_tr8<64>(smem, KL, 32 * s, 16 * mt, lane);
                 s2acc[mt] = mfma3(kh, kl, vh, vl, s2acc[mt]);
             }
         }
@@ -317,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             for (int mt = 0; mt < 4; ++mt) {
                 bf16x4 hi, lo;
                 split4(s2acc[mt], hi, lo);
-                const int off = img_off(16 * w + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
+                const int off = img_off<64>(16 * w + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
                 *reinterpret_cast<bf16x4*>(smem + S2H + off) = hi;
                 *reinterpret_cast<bf16x4*>(smem + S2L + off) = lo;
             }

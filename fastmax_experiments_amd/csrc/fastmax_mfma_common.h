@@ -1,0 +1,177 @@
+// Shared MFMA / LDS-image helpers for the fastmax matrix-core kernels (gfx950).
+#pragma once
+#include "fastmax_common.h"
+
+namespace fastmax {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Byte offset of 16-byte chunk `chunk` of row `row` in a swizzled row-major bf16 image with DP columns.
+//   DP = 64 : 128-byte rows, chunk ^ (row & 7)
+//   DP = 128: 256-byte rows, chunk ^ 2*(row & 7)
+// Both are conflict-free for ds_read_b128 row reads (lane = row) and for ds_read_b64_tr_b16 blocks of
+// 4 rows x 16 columns taken at rows 4q+{0..3} / 16+4q+{0..3} (see tools/mfma_probe.hip).
+template <int DP> __device__ __forceinline__ int img_off(int row, int chunk) {
+    if constexpr (DP == 64) return row * 128 + (((chunk ^ row) & 7) << 4);
+    else return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+}
+
+__device__ __forceinline__ void split4(const f32x4 x, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)x[i];
+        lo[i] = (__bf16)(x[i] - (float)hi[i]);
+    }
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 x) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (__bf16)x[i];
+    return o;
+}
+__device__ __forceinline__ bf16x8 cat4(const bf16x4 a, const bf16x4 b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int DP> __device__ __forceinline__ bf16x8 ld_row8(const char* smem, int base, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(smem + base + img_off<DP>(row, chunk));
+}
+
+// Row fragment in the PERMUTED k order (elements 0..3 = columns col0+4q.., 4..7 = col0+16+4q..): the
+// partner of an operand that comes from accumulator tiles or from a transposed read.
+template <int DP> __device__ __forceinline__ bf16x8 ld_row8_perm(const char* smem, int base, int row, int col0, int q) {
+    const int e0 = col0 + 4 * q, e1 = e0 + 16;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(smem + base + img_off<DP>(row, e0 >> 3) + ((e0 & 7) << 1));
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(smem + base + img_off<DP>(row, e1 >> 3) + ((e1 & 7) << 1));
+    return cat4(a, b);
+}
+
+// Transposed fragment: lane (r = lane&15, q = lane>>4) receives, for image column col0 + r, the 8 rows
+// row0 + 4q + {0..3} and row0 + 16 + 4q + {0..3}.  Address lanes: lane 4q'+p' of a 16-lane group supplies
+// row q' of the 4-row block, columns 4p'..4p'+3.
+template <int DP> __device__ __forceinline__ bf16x8 ld_tr8(const char* smem, int base, int row0, int col0, int lane) {
+    const int q = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int ra = row0 + 4 * q + qq, rb = ra + 16;
+    const int chunk = (col0 >> 3) + (pp >> 1), half = (pp & 1) << 3;
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP>(ra, chunk) + half));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP>(rb, chunk) + half));
+    return u.v;
+}
+
+__device__ __forceinline__ f32x4 mfma(const bf16x8 a, const bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// three-term split product (A = Ah + Al, B = Bh + Bl; Al.Bl dropped): ~2^-16 relative
+__device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
+    c = mfma(ah, bh, c);
+    c = mfma(al, bh, c);
+    c = mfma(ah, bl, c);
+    return c;
+}
+// operand with NP parts (1 = exact bf16 data, 2 = hi + lo split)
+template <int NP> struct Frag { bf16x8 p[NP]; };
+template <int NA, int NB>
+__device__ __forceinline__ f32x4 mfma_parts(const Frag<NA>& a, const Frag<NB>& b, f32x4 c) {
+    c = mfma(a.p[0], b.p[0], c);
+    if constexpr (NA == 2) c = mfma(a.p[1], b.p[0], c);
+    if constexpr (NB == 2) c = mfma(a.p[0], b.p[1], c);
+    return c;
+}
+
+// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
+__device__ __forceinline__ float row16_sum_to_lane15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    return v;
+}
+
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename TIN> struct InTraits;
+template <> struct InTraits<float> { static constexpr int EPL = 4, NP = 2; };
+template <> struct InTraits<bf16_t> { static constexpr int EPL = 8, NP = 1; };
+template <> struct InTraits<f16_t> { static constexpr int EPL = 8, NP = 2; };
+
+// one 16-byte load of row `row` (clamped) at element column c*EPL; zero outside the tensor
+template <typename TIN>
+__device__ __forceinline__ u32x4 load_piece(const TIN* base, int64_t sn, int row, int nrows, int c, int D) {
+    constexpr int EPL = InTraits<TIN>::EPL;
+    const bool ok = row < nrows && c * EPL < D;
+    const int rr = row < nrows ? row : nrows - 1;
+    const int cc = c * EPL < D ? c : 0;
+    u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)rr * sn + cc * EPL);
+    if (!ok) v = u32x4{0, 0, 0, 0};
+    return v;
+}
+
+// write one staged piece into the bf16 image(s) of a tile; part p lives at base + p*IMG
+template <int DP, typename TIN>
+__device__ __forceinline__ void stage_piece(char* smem, int base, int row, int c, const u32x4 raw) {
+    constexpr int IMG = 64 * DP * 2;
+    if constexpr (sizeof(TIN) == 4) {
+        bf16x4 hi, lo;
+        split4(__builtin_bit_cast(f32x4, raw), hi, lo);
+        const int off = img_off<DP>(row, c >> 1) + ((c & 1) << 3);
+        *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
+        *reinterpret_cast<bf16x4*>(smem + base + IMG + off) = lo;
+    } else if constexpr (InTraits<TIN>::NP == 1) {
+        *reinterpret_cast<u32x4*>(smem + base + img_off<DP>(row, c)) = raw;
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 hv = __builtin_bit_cast(h8, raw);
+        f32x4 x0, x1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = (float)hv[i]; x1[i] = (float)hv[4 + i]; }
+        bf16x4 h0, l0, h1, l1;
+        split4(x0, h0, l0);
+        split4(x1, h1, l1);
+        const int off = img_off<DP>(row, c);
+        *reinterpret_cast<bf16x8*>(smem + base + off) = cat4(h0, h1);
+        *reinterpret_cast<bf16x8*>(smem + base + IMG + off) = cat4(l0, l1);
+    }
+}
+
+__device__ __forceinline__ void store4_any(void* base, int dtype, int64_t idx, const f32x4 v) {
+    if (dtype == FASTMAX_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+    else if (dtype == FASTMAX_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = to_bf16x4(v);
+    else {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + idx) = o;
+    }
+}
+
+
+// Stage a wave's 16 x DP fp32 accumulator tile (lane = row r, acc[dt][reg] = column 16dt + 4q4 + reg)
+// through a private LDS area and write it out as whole rows in `dtype`.
+template <int DP>
+__device__ __forceinline__ void store_tile16(char* ost, const f32x4 (&acc)[DP / 16], float scale, int lane, void* out,
+                                             int dtype, int64_t row0_elem, int first_row, int nrows, int D) {
+    constexpr int C16 = DP / 4, DT = DP / 16;
+    const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c16 = 4 * dt + q4;
+        *reinterpret_cast<f32x4*>(ost + r * (DP * 4) + (((c16 ^ r) & (C16 - 1)) << 4)) = acc[dt] * scale;
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * C16) / 64; ++u) {
+        const int idx = u * 64 + lane, rl = idx / C16, c16 = idx % C16;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ost + rl * (DP * 4) + (((c16 ^ rl) & (C16 - 1)) << 4));
+        if (first_row + rl < nrows && 4 * c16 < D)
+            store4_any(out, dtype, row0_elem + (int64_t)rl * D + 4 * c16, val);
+    }
+}
+
+}  // namespace fastmax

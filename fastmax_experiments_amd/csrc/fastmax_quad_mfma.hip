@@ -1,0 +1,203 @@
+// fastmax forward as masked / unmasked polynomial attention tiles on the matrix cores (gfx950):
+//     o_i = sum_j f(a q_i.k_j) v_j / g_i ,  g_i = sum_j f(a q_i.k_j)   (j <= i when causal)
+// f(s) = 1+s (p=1) or 1+s+s^2/2 (p=2).  Same function as the reference's factorised sums
+// (attention_mechanisms/fastmax.py:184-322); for p=2 the factorised form costs ~4 D^2 (D+1) flop per
+// token against ~4 D N/2 here, so below N ~ 2 D^2 (every configuration in BASELINE.json) this is the
+// cheaper evaluation, and it needs no D^2 x (D+1) third-order state.  Also serves the unmasked and
+// N_q != N_k (KV-cache decode) cases for both p.
+//
+// One workgroup = 64 queries of one (b,h) head (wave w: queries 16w..16w+15), looping over 64-key tiles:
+//   (1) S^T = K Q^T        MFMA 16x16x32 bf16, A = K rows (ds_read_b128), B = Q rows
+//   P = f(a S) * mask, split hi/lo in registers (accumulator layout = next B operand, permuted k)
+//   (2) O^T += V^T P^T     A = V^T by ds_read_b64_tr_b16 of the row-major V image
+// fp32 / fp16 inputs are carried as bf16 hi + lo parts (3-term products, ~2^-16 relative); bf16 inputs
+// are exact single parts.  Head sizes are padded to DP = 64 or 128 columns inside LDS only.
+#include "fastmax_mfma_common.h"
+
+namespace fastmax {
+
+struct QuadMfmaParams {
+    const void *q, *k, *v;
+    Strides3 qs, ks, vs;
+    void* o;
+    float* g;
+    int H, Nq, Nk, D, causal, out_dtype;
+    float a, g0;
+};
+
+// grid = (ceil(Nq/64), B*H), block = 256, dynamic LDS = 3*NP*64*DP*2 bytes
+template <int DP, int P, typename TIN>
+__global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int IMG = 64 * DP * 2;
+    constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG;
+    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = 64 / RPP;
+    constexpr int KS = DP / 32, DT = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int D = prm.D, Nq = prm.Nq, Nk = prm.Nk;
+    const bool causal = prm.causal != 0;
+    const int nqt = gridDim.x;
+    const int qt = causal ? nqt - 1 - (int)blockIdx.x : (int)blockIdx.x;      // causal: heaviest query tiles first
+    const int i0 = qt * 64;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    // Q tile -> images (once)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = srow + ps * RPP;
+        stage_piece<DP, TIN>(smem, QI, row, scol, load_piece<TIN>(qb, prm.qs.sn, i0 + row, Nq, scol, D));
+    }
+    u32x4 rk[NPASS], rv[NPASS];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = kt * 64 + srow + ps * RPP;
+            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, Nk, scol, D);
+            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, Nk, scol, D);
+        }
+    };
+    const int nkt = causal ? qt + 1 : (Nk + 63) / 64;
+    issue(0);
+    __syncthreads();
+    Frag<NP> qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) qf[ks].p[p] = ld_row8<DP>(smem, QI + p * IMG, 16 * w + r, 4 * ks + q4);
+
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+    float gsum = 0.f;
+    const int qidx = i0 + 16 * w + r;
+    const float a = prm.a;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                   // previous tile fully consumed
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
+        }
+        if (kt + 1 < nkt) issue(kt + 1);
+        __syncthreads();
+        const bool diag = causal && kt == qt;
+        Frag<2> pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 pt[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jt = 2 * s + e;
+                f32x4 sc = {0, 0, 0, 0};
+                if (!(diag && jt > w)) {                   // wave-uniform
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        Frag<NP> kf;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) kf.p[p] = ld_row8<DP>(smem, KI + p * IMG, 16 * jt + r, 4 * ks + q4);
+                        sc = mfma_parts<NP, NP>(kf, qf[ks], sc);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = kt * 64 + 16 * jt + 4 * q4 + i;
+                    const bool keep = key < Nk && (!causal || key <= qidx);
+                    const float pv = keep ? poly_f<P>(a * sc[i]) : 0.f;
+                    gsum += pv;
+                    pt[e][i] = pv;
+                }
+            }
+            bf16x4 h0, l0, h1, l1;
+            split4(pt[0], h0, l0);
+            split4(pt[1], h1, l1);
+            pf[s].p[0] = cat4(h0, h1);
+            pf[s].p[1] = cat4(l0, l1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!(diag && 2 * s > w)) {                    // wave-uniform
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    Frag<NP> vf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) vf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
+                    oacc[dt] = mfma_parts<NP, 2>(vf, pf[s], oacc[dt]);
+                }
+            }
+        }
+    }
+    gsum += __shfl_xor(gsum, 16, 64);
+    gsum += __shfl_xor(gsum, 32, 64);
+    // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
+    const float gval = causal ? gsum : gsum - (float)Nk + prm.g0;
+    const float ginv = 1.0f / gval;
+    if (qidx < Nq && prm.g && q4 == 0) prm.g[(int64_t)bh * Nq + qidx] = gval;
+
+    // stage the wave's 16 x DP fp32 tile through the (now free) K/V image area -> whole-row stores
+    __syncthreads();
+    char* ost = smem + KI + w * (16 * DP * 4);
+    constexpr int C16 = DP / 4;                            // 16-byte chunks per staged row
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c16 = 4 * dt + q4;
+        *reinterpret_cast<f32x4*>(ost + r * (DP * 4) + (((c16 ^ r) & (C16 - 1)) << 4)) = oacc[dt] * ginv;
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * C16) / 64; ++u) {
+        const int idx = u * 64 + lane, rl = idx / C16, c16 = idx % C16;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ost + rl * (DP * 4) + (((c16 ^ rl) & (C16 - 1)) << 4));
+        const int go = i0 + 16 * w + rl;
+        if (go < Nq && 4 * c16 < D) store4_any(prm.o, prm.out_dtype, ((int64_t)bh * Nq + go) * D + 4 * c16, val);
+    }
+}
+
+template <int DP, int P, typename TIN>
+static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP;
+    constexpr int lds = 3 * NP * 64 * DP * 2;
+    auto kern = fwd_quad_mfma_kernel<DP, P, TIN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((prm.Nq + 63) / 64, B * prm.H), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, prm);
+    return (int)hipGetLastError();
+}
+template <int P, typename TIN>
+static int launch_quad_d(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+    return prm.D <= 64 ? launch_quad_t<64, P, TIN>(prm, B, stream) : launch_quad_t<128, P, TIN>(prm, B, stream);
+}
+template <typename TIN>
+static int launch_quad_p(const QuadMfmaParams& prm, int B, int p, hipStream_t stream) {
+    return p == 1 ? launch_quad_d<1, TIN>(prm, B, stream) : launch_quad_d<2, TIN>(prm, B, stream);
+}
+
+bool quad_mfma_supported(const fastmax_problem& p) {
+    const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
+    return (p.D % epl) == 0 && p.D <= 128 && p.Nq >= 16;
+}
+
+int launch_fwd_quad_mfma(const FwdArgs& a) {
+    if (!quad_mfma_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    QuadMfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D,
+                       a.prob.causal, a.prob.out_dtype, a.prob.a, a.prob.g0};
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return launch_quad_p<float>(prm, a.prob.B, a.prob.p, a.stream);
+        case FASTMAX_BF16: return launch_quad_p<bf16_t>(prm, a.prob.B, a.prob.p, a.stream);
+        case FASTMAX_F16: return launch_quad_p<f16_t>(prm, a.prob.B, a.prob.p, a.stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

@@ -50,7 +50,8 @@ enum fastmax_path {
     FASTMAX_PATH_AUTO = 0,
     FASTMAX_PATH_QUADRATIC = 1,  /* masked/unmasked f(QK^T)V tiles on the vector ALU, any p, any D<=128 */
     FASTMAX_PATH_RECURRENT = 2,  /* p=1 masked, carried K^T V' state, vector ALU, linear in N */
-    FASTMAX_PATH_MFMA = 3        /* p=1 masked, chunked scan on the matrix cores (split-bf16), D in {32,64,128} */
+    FASTMAX_PATH_MFMA = 3,       /* p=1 masked, chunked scan on the matrix cores (split-bf16), linear in N */
+    FASTMAX_PATH_QUADRATIC_MFMA = 4 /* f(QK^T)V tiles on the matrix cores: p=2, unmasked, N_q != N_k */
 };
 
 typedef struct fastmax_problem {

@@ -38,9 +38,12 @@ def test_problem_validation_without_gpu(lib):
     ok = Problem(2, 4, 256, 256, 64, 0, 0, 1, 1, 1 / 64, 1 / 8192, 256.0, PATH_AUTO)
     assert lib.fastmax_hip_select_path(ctypes.byref(ok)) in (PATH_RECURRENT, PATH_MFMA)
     p2 = Problem(2, 4, 256, 256, 64, 0, 0, 2, 1, 1 / 64, 1 / 8192, 256.0, PATH_AUTO)
-    assert lib.fastmax_hip_select_path(ctypes.byref(p2)) == PATH_QUADRATIC
+    from fastmax_experiments_amd._lib import PATH_QUADRATIC_MFMA
+    assert lib.fastmax_hip_select_path(ctypes.byref(p2)) == PATH_QUADRATIC_MFMA
     unm = Problem(2, 4, 1, 16, 64, 0, 0, 1, 0, 1 / 64, 1 / 8192, 1.0, PATH_AUTO)
-    assert lib.fastmax_hip_select_path(ctypes.byref(unm)) == PATH_QUADRATIC
+    assert lib.fastmax_hip_select_path(ctypes.byref(unm)) == PATH_QUADRATIC           # N_q < 16: vector-ALU tiles
+    odd = Problem(2, 4, 64, 64, 50, 0, 0, 2, 1, 1.0, 1.0, 0.0, PATH_AUTO)             # D % 4 != 0
+    assert lib.fastmax_hip_select_path(ctypes.byref(odd)) == PATH_QUADRATIC
     bad_p = Problem(2, 4, 256, 256, 64, 0, 0, 3, 1, 1.0, 1.0, 0.0, PATH_AUTO)
     assert lib.fastmax_hip_select_path(ctypes.byref(bad_p)) == -1
     bad_shape = Problem(2, 4, 5, 16, 64, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_AUTO)      # causal, Nq != Nk

@@ -31,13 +31,14 @@ def _kw(meta):
     return dict(meta.get("kw", {}))
 
 
-PATHS = ["auto", "quadratic", "recurrent", "mfma"]
+PATHS = ["auto", "quadratic", "recurrent", "mfma", "quadratic_mfma"]
 
 
 def _force(path):
     from fastmax_experiments_amd import _lib, ops
     ops.set_forced_path({"auto": _lib.PATH_AUTO, "quadratic": _lib.PATH_QUADRATIC,
-                         "recurrent": _lib.PATH_RECURRENT, "mfma": _lib.PATH_MFMA}[path])
+                         "recurrent": _lib.PATH_RECURRENT, "mfma": _lib.PATH_MFMA,
+                         "quadratic_mfma": _lib.PATH_QUADRATIC_MFMA}[path])
 
 
 @pytest.fixture(autouse=True)
@@ -73,6 +74,47 @@ def test_golden_forward_each_kernel_family(name, path):
         pytest.skip("matrix-core kernel does not cover this head size")
     o = fastmax(q, k, v, mask=True, p=1, **_kw(meta))
     assert rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("path", ["quadratic", "quadratic_mfma"])
+@pytest.mark.parametrize("name", [n for n in golden_names("fm_") if "N1D" not in n and "N7D" not in n] +
+                         ["opt_tensors_normalized_p2", "opt_normalize_term_3_p2_unmasked"])
+def test_golden_forward_quadratic_families(name, path):
+    """every p / mask combination through the vector-ALU and the matrix-core tile kernels"""
+    from attention_mechanisms.fastmax import fastmax
+    d, meta = load_golden(name)
+    _force(path)
+    o = fastmax(*(_t(d[n]) for n in "qkv"), mask=meta["mask"], p=meta["p"], **_kw(meta))
+    assert rel_err(o.cpu().numpy(), d["o"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 8e-3), (torch.float16, 2e-3), (torch.float32, TOL_FWD)])
+@pytest.mark.parametrize("shape,p,mask", [((2, 3, 200, 64), 2, True), ((1, 2, 130, 128), 2, True), ((1, 2, 96, 32), 2, True),
+                                          ((2, 2, 100, 64), 1, False), ((1, 2, 257, 128), 2, False), ((1, 2, 70, 80), 2, True)])
+def test_matrix_core_tiles_dtypes_and_head_sizes(shape, p, mask, dt, tol):
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2])
+    q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
+    qq, kk, vv = q.cuda(), k.cuda(), v.cuda()
+    assert ops.selected_path(qq, kk, p, mask) == _lib.PATH_QUADRATIC_MFMA
+    o = fastmax(qq, kk, vv, mask=mask, p=p)
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=mask, p=p)
+    assert rel_err(o.float().cpu().numpy(), ro) < tol
+
+
+def test_decode_shapes_matrix_core_tiles():
+    # N_q != N_k, unmasked (KV-cache prefill/decode shapes, model.py:427-430,464-466)
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import fastmax_oracle as orc
+    g = torch.Generator().manual_seed(9)
+    for nq, nk in ((16, 100), (64, 64), (100, 333)):
+        q, k, v = torch.randn(2, 2, nq, 64, generator=g), torch.randn(2, 2, nk, 64, generator=g), torch.randn(2, 2, nk, 64, generator=g)
+        for p in (1, 2):
+            o = fastmax(q.cuda(), k.cuda(), v.cuda(), mask=False, p=p)
+            ro, _ = orc.fastmax_fwd_dense(q.numpy(), k.numpy(), v.numpy(), mask=False, p=p)
+            assert rel_err(o.cpu().numpy(), ro) < TOL_FWD
 
 
 def test_c1_baseline_config():
@@ -191,6 +233,27 @@ def test_low_precision_backward(dt):
         tol = 2e-2 if dt == torch.bfloat16 else 4e-3
         for t, r in zip((qq, kk, vv), e):
             assert rel_err(t.grad.float().cpu().numpy(), r) < tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_BWD), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("shape,p,mask", [((2, 3, 200, 64), 2, True), ((1, 2, 130, 128), 2, True), ((1, 2, 96, 32), 1, True),
+                                          ((2, 2, 100, 64), 1, False), ((1, 2, 257, 128), 2, False), ((1, 2, 70, 80), 2, True),
+                                          ((1, 1, 5, 16), 2, True)])
+def test_backward_matrix_core_vs_vector_alu_vs_oracle(shape, p, mask, dt, tol):
+    """dQ, dK, dV: matrix-core tiles and the vector-ALU family against the C oracle (fp64)"""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2] + p)
+    q, k, v, go = (torch.randn(shape, generator=g).to(dt) for _ in range(4))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
+    for path in ("auto", "quadratic"):
+        _force(path)
+        qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = fastmax(qq, kk, vv, mask=mask, p=p)
+        o.backward(go.cuda().to(o.dtype))
+        for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+            assert t.grad.dtype == dt
+            assert rel_err(t.grad.float().cpu().numpy(), rr) < tol, (path, n)
 
 
 def test_cpu_tensors_round_trip_like_model_py():

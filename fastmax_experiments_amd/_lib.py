@@ -18,7 +18,7 @@ E_BAD_P = -1
 SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_backward_workspace",
            "fastmax_hip_backward", "fastmax_hip_normalize_workspace", "fastmax_hip_normalize",
            "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string",
-           "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
+           "fastmax_hip_normalize_stats", "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
 
 
 class Problem(ctypes.Structure):
@@ -57,6 +57,10 @@ def lib():
     L.fastmax_hip_normalize_workspace.restype = sz
     L.fastmax_hip_normalize.argtypes = [vp, i64p, ci, fp, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize.restype = ci
+    L.fastmax_hip_normalize_stats.argtypes = [vp, i64p, ci, fp, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_stats.restype = ci
+    L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp]
+    L.fastmax_hip_linearmax_forward.restype = ci
     i64 = ctypes.c_int64
     L.fastmax_hip_nf4_linear_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp]
     L.fastmax_hip_nf4_linear_forward.restype = ci

@@ -43,8 +43,16 @@ def fastmax_hack(q, k, v, p=1, mask=True):
     home, in_dtype = q.device, q.dtype
     kdt = in_dtype if in_dtype in _KERNEL_DTYPES else torch.float32
     qd, kd = (ops._prep(t.to(kdt), dev) for t in (q, k))
-    vd = v.to(device=dev, dtype=torch.float32)
-    qn, kn = _NormalizeQK.apply(qd), _NormalizeQK.apply(kd)
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v))
+    if mask and p == 1 and not needs_grad:
+        # inference / forward-only: prologue fused into the matrix-core kernel, one pass over Q, K, V
+        o = ops.linearmax_forward_fused(qd, kd, ops._prep(v.to(kdt), dev))
+        if o is not None:
+            return o.to(device=home, dtype=in_dtype)
+    # training (or shapes the fused kernel does not cover): prologue and attention as separate autograd nodes,
+    # both in libfastmax_hip.so; 16-bit inputs keep their dtype between the two, like the reference
+    vd = ops._prep(v.to(kdt), dev)
+    qn, kn = _NormalizeQK.apply(qd).to(kdt), _NormalizeQK.apply(kd).to(kdt)
     if not mask:
         # fastmax_hack.py:6-33: first order whatever p is; constant term N_k; result float32 for
         # low-precision inputs (float32 ones at line 21), float64 stays float64
@@ -61,6 +69,7 @@ class _UnmaskedNk(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, g0):
+        q, k, v = q.float(), k.float(), v.float()
         o, g = ops.forward(ops._prep(q, q.device), ops._prep(k, q.device), ops._prep(v, q.device), 1, False, 1.0,
                            g0, torch.float32)
         ctx.save_for_backward(q, k, v, o, g)

@@ -20,8 +20,9 @@ int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_QUADRATIC_MFMA) return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_E_BAD_SHAPE;
     const bool lin = (p.p == 1 && p.causal);
     if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
-    if (p.path == FASTMAX_PATH_MFMA) return (lin && mfma_p1_supported(p)) ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
-    if (lin) return mfma_p1_supported(p) ? FASTMAX_PATH_MFMA : FASTMAX_PATH_RECURRENT;
+    const bool lin_mfma = lin && (mfma_p1_supported(p) || mfma_gen_supported(p, false));
+    if (p.path == FASTMAX_PATH_MFMA) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
+    if (lin) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_PATH_RECURRENT;
     return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_PATH_QUADRATIC;
 }
 bool aligned16(const void* ptr, const int64_t* s, int dtype) {
@@ -81,7 +82,7 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
     switch (path) {
-        case FASTMAX_PATH_MFMA: return launch_fwd_mfma_p1(a);
+        case FASTMAX_PATH_MFMA: return mfma_p1_supported(*prob) ? launch_fwd_mfma_p1(a) : launch_fwd_mfma_gen(a, nullptr, nullptr);
         case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
         case FASTMAX_PATH_QUADRATIC_MFMA: return launch_fwd_quad_mfma(a);
         default: return launch_fwd_quadratic(a);
@@ -122,6 +123,30 @@ int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype, fl
     if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
     return launch_normalize(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, workspace,
                             reinterpret_cast<hipStream_t>(stream));
+}
+
+int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dtype, float* inv_norm, int B, int H, int N,
+                                int D, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !x_strides || !inv_norm) return FASTMAX_E_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
+    return launch_normalize_stats(x, st(x_strides), dtype, inv_norm, B, H, N, D, workspace,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                                  const int64_t* k_strides, const void* v, const int64_t* v_strides,
+                                  const float* q_inv_norm, const float* k_inv_norm, void* o, float* g, void* stream) {
+    int rc = validate(prob);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides || !q_inv_norm || !k_inv_norm) return FASTMAX_E_NULL;
+    if (!mfma_gen_supported(*prob, true)) return FASTMAX_E_BAD_SHAPE;
+    if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
+          aligned16(v, v_strides, prob->in_dtype)) || (reinterpret_cast<uintptr_t>(o) & 15))
+        return FASTMAX_E_ALIGNMENT;
+    FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, nullptr, 0,
+              reinterpret_cast<hipStream_t>(stream)};
+    return launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }
 
 }  // extern "C"

@@ -526,6 +526,30 @@ static int launch_normalize_t(const void* x, Strides3 xs, float* y, float* inv_n
     hipLaunchKernelGGL((normalize_apply_kernel<T>), grid, block, 0, stream, x, xs, H, N, D, maxbits, y, inv_norm);
     return (int)hipGetLastError();
 }
+__global__ void normalize_finish_kernel(const unsigned int* maxbits, float* inv_norm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv_norm[i] = 1.0f / sqrtf(__uint_as_float(maxbits[i]));
+}
+template <typename T>
+static int launch_stats_t(const void* x, Strides3 xs, float* inv_norm, int B, int H, int N, int D, void* ws,
+                          hipStream_t stream) {
+    unsigned int* maxbits = reinterpret_cast<unsigned int*>(ws);
+    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 3) / 4, B * H), dim3(256), 0, stream, x, xs, H, N, D, maxbits);
+    hipLaunchKernelGGL(normalize_finish_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, maxbits, inv_norm, B * H);
+    return (int)hipGetLastError();
+}
+int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
+                           void* workspace, hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: return launch_stats_t<float>(x, xs, inv_norm, B, H, N, D, workspace, stream);
+        case FASTMAX_BF16: return launch_stats_t<bf16_t>(x, xs, inv_norm, B, H, N, D, workspace, stream);
+        case FASTMAX_F16: return launch_stats_t<f16_t>(x, xs, inv_norm, B, H, N, D, workspace, stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
 int launch_normalize(const void* x, Strides3 xs, int dtype, float* y, float* inv_norm, int B, int H, int N, int D,
                      void* workspace, hipStream_t stream) {
     switch (dtype) {

@@ -57,7 +57,9 @@ def _problem(q, k, in_dt, out_dt, p, causal, nt, g0):
 
 
 def selected_path(q, k, p, causal, nt=1.0):
-    prob = _problem(q, k, q.dtype if q.dtype in _DT else torch.float32, torch.float32, p, causal, nt, 0.0)
+    in_dt = q.dtype if q.dtype in _DT else torch.float32
+    out_dt = in_dt if causal else torch.float32          # dtype rule Q1
+    prob = _problem(q, k, in_dt, out_dt, p, causal, nt, 0.0)
     return _lib.lib().fastmax_hip_select_path(ctypes.byref(prob))
 
 
@@ -114,6 +116,41 @@ def normalize(x):
                                      D, wsp, wsb.numel(), _stream(dev))
     _lib.check(rc, "fastmax_hip_normalize")
     return y, inv
+
+
+def normalize_stats(x):
+    """1 / max_n ||x_n - mean_D x_n|| per (b,h) -- the only global quantity of the linearmax prologue."""
+    L = _lib.lib()
+    dev = x.device
+    B, H, N, D = x.shape
+    inv = torch.empty((B, H), dtype=torch.float32, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_workspace(B, H), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_normalize_stats(x.data_ptr(), _strides(x), _DT[x.dtype], inv.data_ptr(), B, H, N, D, wsp,
+                                           wsb.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_normalize_stats")
+    return inv
+
+
+def linearmax_forward_fused(q, k, v):
+    """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
+    Returns None when the shape / dtype is not covered (the caller then uses the unfused route)."""
+    L = _lib.lib()
+    dev = q.device
+    B, H, N, D = q.shape
+    if q.dtype not in _DT or D > 128:
+        return None
+    prob = _problem(q, k, q.dtype, q.dtype, 1, True, 1.0, 0.0)
+    qi, ki = normalize_stats(q), normalize_stats(k)
+    o = torch.empty((B, H, N, D), dtype=q.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_linearmax_forward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                             v.data_ptr(), _strides(v), qi.data_ptr(), ki.data_ptr(), o.data_ptr(), None,
+                                             _stream(dev))
+    if rc in (-2, -5):          # FASTMAX_E_BAD_SHAPE / _ALIGNMENT: not covered by the fused kernel
+        return None
+    _lib.check(rc, "fastmax_hip_linearmax_forward")
+    return o
 
 
 def effective_normalize_term(D, normalize_term, tensors_normalized):

@@ -104,6 +104,22 @@ size_t fastmax_hip_normalize_workspace(int B, int H);
 int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype,
                           float* y, float* inv_norm, int B, int H, int N, int D,
                           void* workspace, size_t workspace_bytes, void* stream);
+/*      statistics only: inv_norm[b,h] = 1 / max_n ||x_n - mean_D x_n||  (no normalised copy is written) */
+int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dtype, float* inv_norm,
+                                int B, int H, int N, int D, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
+/* ---- fused linearmax forward: fastmax_hack.py:36-60 (masked branch) in one pass over Q, K, V --
+ *      the mean-centre / max-norm prologue is applied to the Q and K rows as they are staged, with the
+ *      per-(b,h) scales from fastmax_hip_normalize_stats; then first-order masked fastmax with nt = 1
+ *      (prob->a = 1, prob->p = 1, prob->causal = 1).  Returns FASTMAX_E_BAD_SHAPE when the shape is not
+ *      covered by the matrix-core kernel (the caller then runs normalize + forward separately).     */
+int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
+                                  const void* q, const int64_t* q_strides,
+                                  const void* k, const int64_t* k_strides,
+                                  const void* v, const int64_t* v_strides,
+                                  const float* q_inv_norm, const float* k_inv_norm,
+                                  void* o, float* g, void* stream);
 
 /* ---- QLoRA linear: frozen NF4 base weight + LoRA branch, fused (csrc/nf4_lora.hip).
  *      Replaces the bitsandbytes Linear4bit matmul + the low-rank branch of

@@ -256,6 +256,46 @@ def test_backward_matrix_core_vs_vector_alu_vs_oracle(shape, p, mask, dt, tol):
             assert rel_err(t.grad.float().cpu().numpy(), rr) < tol, (path, n)
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("shape", [(2, 3, 200, 64), (1, 2, 1000, 32), (1, 2, 130, 16), (1, 2, 257, 48), (2, 2, 65, 64),
+                                   (1, 2, 300, 128), (1, 2, 129, 96)])
+def test_linear_time_matrix_core_kernel_dtypes_and_head_sizes(shape, dt, tol):
+    """p=1 masked through the generic chunked-scan kernel (padded head sizes, 16-bit inputs, D=128 for bf16)"""
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
+    qq, kk, vv = q.cuda(), k.cuda(), v.cuda()
+    want = _lib.PATH_MFMA if (shape[3] <= 64 or dt == torch.bfloat16) else _lib.PATH_RECURRENT
+    assert ops.selected_path(qq, kk, 1, True) == want
+    o = fastmax(qq, kk, vv)
+    assert o.dtype == dt
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy())
+    assert rel_err(o.float().cpu().numpy(), ro) < tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-4), (torch.bfloat16, 1.5e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("shape", [(2, 3, 200, 64), (1, 4, 1024, 32), (1, 2, 333, 128), (1, 2, 70, 80)])
+def test_linearmax_fused_prologue(shape, dt, tol):
+    """fastmax_hack masked, forward only: prologue fused into the kernel (where covered) vs the fp64 oracle"""
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    from oracle import fastmax_oracle as orc
+    g = torch.Generator().manual_seed(shape[2])
+    q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
+    with torch.no_grad():
+        o = fastmax_hack(q.cuda(), k.cuda(), v.cuda(), p=1, mask=True)
+    assert o.dtype == dt
+    ro = orc.linearmax_fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), chunk=64)
+    assert rel_err(o.float().cpu().numpy(), ro) < tol
+    # the autograd (unfused) route computes the same function
+    qq = q.cuda().requires_grad_(True)
+    o2 = fastmax_hack(qq, k.cuda(), v.cuda(), p=1, mask=True)
+    assert rel_err(o2.detach().float().cpu().numpy(), ro) < tol
+    o2.float().sum().backward()
+    assert qq.grad is not None and qq.grad.dtype == dt and torch.isfinite(qq.grad).all()
+
+
 def test_cpu_tensors_round_trip_like_model_py():
     # lit_gpt/model.py:482-486 hands CPU tensors over and calls .cuda() on the result
     from attention_mechanisms.fastmax import fastmax

@@ -59,7 +59,7 @@ def lib():
     L.fastmax_hip_normalize.restype = ci
     L.fastmax_hip_normalize_stats.argtypes = [vp, i64p, ci, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize_stats.restype = ci
-    L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp]
+    L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp, sz, vp]
     L.fastmax_hip_linearmax_forward.restype = ci
     i64 = ctypes.c_int64
     L.fastmax_hip_nf4_linear_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp]

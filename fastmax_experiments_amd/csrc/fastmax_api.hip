@@ -60,7 +60,8 @@ int fastmax_hip_select_path(const fastmax_problem* prob) {
 
 size_t fastmax_hip_forward_workspace(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
-    return select(*prob) == FASTMAX_PATH_MFMA ? mfma_p1_workspace(*prob) : 0;
+    if (select(*prob) != FASTMAX_PATH_MFMA) return 0;
+    return split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128);
 }
 
 int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
@@ -136,7 +137,8 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
 
 int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                   const int64_t* k_strides, const void* v, const int64_t* v_strides,
-                                  const float* q_inv_norm, const float* k_inv_norm, void* o, float* g, void* stream) {
+                                  const float* q_inv_norm, const float* k_inv_norm, void* o, float* g, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     int rc = validate(prob);
     if (rc) return rc;
     if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides || !q_inv_norm || !k_inv_norm) return FASTMAX_E_NULL;
@@ -144,7 +146,7 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
     if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
           aligned16(v, v_strides, prob->in_dtype)) || (reinterpret_cast<uintptr_t>(o) & 15))
         return FASTMAX_E_ALIGNMENT;
-    FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, nullptr, 0,
+    FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
     return launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }

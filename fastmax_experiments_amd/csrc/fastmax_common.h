@@ -105,6 +105,11 @@ int launch_fwd_mfma_gen(const FwdArgs& a, const float* qscale, const float* ksca
 bool mfma_gen_supported(const fastmax_problem& p, bool norm);
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
                            void* workspace, hipStream_t stream);
+// sequence split of the linear-time kernels when B*H alone cannot fill the chip
+struct SplitPlan { int nseg, cps; };
+SplitPlan split_plan(const fastmax_problem& p);
+size_t split_workspace_bytes(const fastmax_problem& p, int dp);
+int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
 int launch_fwd_quad_mfma(const FwdArgs& a);
 bool quad_mfma_supported(const fastmax_problem& p);
 int launch_bwd_quadratic(const BwdArgs& a);

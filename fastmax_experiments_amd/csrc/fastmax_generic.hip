@@ -480,21 +480,47 @@ int launch_bwd_quadratic(const BwdArgs& a) {
 // ------------------------------------------------------------------------------------------
 // linearmax prologue (fastmax.py:326-334): one wave per token
 // ------------------------------------------------------------------------------------------
+// max over tokens of the squared centred norm.  One block walks TOK tokens of one head: a token row is
+// spread over 16 lanes (DPP row reductions, 4 rows per wave at a time), the running max stays in registers
+// and each block issues ONE atomicMax (token-per-wave with an atomic each serialised on the head's word).
 template <typename T>
 __global__ __launch_bounds__(256) void normalize_max_kernel(const void* x, Strides3 xs, int H, int N, int D,
                                                             unsigned int* maxbits) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int TOK = 1024;
+    __shared__ float wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, rgrp = tid >> 4;                 // 16 lanes per row, 16 rows per block pass
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
-    const float x0 = lane < D ? to_float(row[lane]) : 0.f;
-    const float x1 = lane + 64 < D ? to_float(row[lane + 64]) : 0.f;
-    const float mean = wave_sum(x0 + x1) / (float)D;
-    const float c0 = lane < D ? x0 - mean : 0.f, c1 = lane + 64 < D ? x1 - mean : 0.f;
-    const float nn = wave_sum(c0 * c0 + c1 * c1);
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    float best = 0.f;
+    for (int n = n_begin + rgrp; n < n_end; n += 16) {
+        const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = sub + 16 * e;
+            v[e] = d < D ? to_float(row[d]) : 0.f;
+            s += v[e];
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)D;
+        float nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = (sub + 16 * e) < D ? v[e] - mean : 0.f;
+            nn = fmaf(c, c, nn);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) nn += __shfl_xor(nn, off, 64);
+        best = fmaxf(best, nn);
+    }
+    best = wave_max(best);
+    if (lane == 0) wmax[wave] = best;
+    __syncthreads();
     // squared norms are >= 0, so their float bit patterns order like unsigned integers
-    if (lane == 0) atomicMax(&maxbits[bh], __float_as_uint(nn));
+    if (tid == 0) atomicMax(&maxbits[bh], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 template <typename T>
 __global__ __launch_bounds__(256) void normalize_apply_kernel(const void* x, Strides3 xs, int H, int N, int D,
@@ -522,7 +548,7 @@ static int launch_normalize_t(const void* x, Strides3 xs, float* y, float* inv_n
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid((N + 3) / 4, B * H), block(256);
-    hipLaunchKernelGGL((normalize_max_kernel<T>), grid, block, 0, stream, x, xs, H, N, D, maxbits);
+    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 1023) / 1024, B * H), block, 0, stream, x, xs, H, N, D, maxbits);
     hipLaunchKernelGGL((normalize_apply_kernel<T>), grid, block, 0, stream, x, xs, H, N, D, maxbits, y, inv_norm);
     return (int)hipGetLastError();
 }
@@ -536,7 +562,7 @@ static int launch_stats_t(const void* x, Strides3 xs, float* inv_norm, int B, in
     unsigned int* maxbits = reinterpret_cast<unsigned int*>(ws);
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 3) / 4, B * H), dim3(256), 0, stream, x, xs, H, N, D, maxbits);
+    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 1023) / 1024, B * H), dim3(256), 0, stream, x, xs, H, N, D, maxbits);
     hipLaunchKernelGGL(normalize_finish_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, maxbits, inv_norm, B * H);
     return (int)hipGetLastError();
 }

@@ -34,6 +34,8 @@ struct MfmaParams {
     float* g;
     int H, N;
     float a;
+    const float* state;   // sequence split: inclusive prefix states [(bh*(nseg-1) + seg-1)][64*64 + 64 + 64], or null
+    int nseg, cps;        // segments per head, chunks per segment
 };
 
 namespace m64 {
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg;
+    const int b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N;
     const float a = prm.a;
 
@@ -93,17 +96,42 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
         }
     };
 
-    // zero the carried state: S2 images, S1V[0], KSUM[0]
-    for (int i = tid; i < (2 * IMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + S2H + 16 * i) = f32x4{0, 0, 0, 0};
-    if (tid < 64) {
-        reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
-        reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
-    }
-    f32x4 s2acc[4];                                                  // S2[16mt + 4q4 + reg][16w + r]
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) s2acc[mt] = f32x4{0, 0, 0, 0};
-
     const int nchunks = (N + C - 1) / C;
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+    f32x4 s2acc[4];                                                  // S2[16mt + 4q4 + reg][16w + r]
+    auto publish_s2 = [&]() {                                        // accumulators -> bf16 hi/lo image rows d = 16w + r
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            bf16x4 hi, lo;
+            split4(s2acc[mt], hi, lo);
+            const int off = img_off<64>(16 * w + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
+            *reinterpret_cast<bf16x4*>(smem + S2H + off) = hi;
+            *reinterpret_cast<bf16x4*>(smem + S2L + off) = lo;
+        }
+    };
+    if (seg == 0) {
+        // zero the carried state: S2 images, S1V[0], KSUM[0]
+        for (int i = tid; i < (2 * IMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + S2H + 16 * i) = f32x4{0, 0, 0, 0};
+        if (tid < 64) {
+            reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
+            reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) s2acc[mt] = f32x4{0, 0, 0, 0};
+    } else {
+        // sequence split: start from the prefix state of all earlier segments
+        const float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + (seg - 1)) * (64 * 64 + 128);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s2acc[mt][i] = rec[(16 * mt + 4 * q4 + i) * 64 + 16 * w + r];
+        publish_s2();
+        if (tid < 64) {
+            reinterpret_cast<float*>(smem + S1V)[64 * (c_begin & 1) + tid] = rec[64 * 64 + tid];
+            reinterpret_cast<float*>(smem + KSUM)[64 * (c_begin & 1) + tid] = rec[64 * 64 + 64 + tid];
+        }
+    }
+
     auto chunk_body = [&](f32x4 (&rq)[4], f32x4 (&rk)[4], f32x4 (&rv)[4], int c) {
         const int n0 = c * C;
         const int cur = c & 1, nxt = cur ^ 1;
@@ -138,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             *reinterpret_cast<f32x4*>(smem + PARTK + (srow * 64 + 4 * scol) * 4) = ck;
             *reinterpret_cast<f32x4*>(smem + PARTV + (srow * 64 + 4 * scol) * 4) = cv;
         }
-        if (c + PF < nchunks) issue_loads(rq, rk, rv, n0 + PF * C);  // refill this register set: PF chunks ahead
+        if (c + PF < c_end) issue_loads(rq, rk, rv, n0 + PF * C);    // refill this register set: PF chunks ahead
         __syncthreads();                                             // B1: images + partial sums visible
 
         // running sums for the NEXT chunk (double-buffered, so readers of `cur` are undisturbed)
@@ -259,31 +287,22 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
         __syncthreads();                                             // B2: every read of this chunk's images is done
 
         // ---- (e) publish the new S2 as bf16 hi/lo image rows d = 16w + r (read after the next B1) ----
-        if (c + 1 < nchunks) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                bf16x4 hi, lo;
-                split4(s2acc[mt], hi, lo);
-                const int off = img_off<64>(16 * w + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
-                *reinterpret_cast<bf16x4*>(smem + S2H + off) = hi;
-                *reinterpret_cast<bf16x4*>(smem + S2L + off) = lo;
-            }
-        }
+        if (c + 1 < c_end) publish_s2();
     };
 
     f32x4 aq[4], ak[4], av[4];
     if constexpr (PF == 1) {
-        issue_loads(aq, ak, av, 0);
+        issue_loads(aq, ak, av, c_begin * C);
         __syncthreads();
-        for (int c = 0; c < nchunks; ++c) chunk_body(aq, ak, av, c);
+        for (int c = c_begin; c < c_end; ++c) chunk_body(aq, ak, av, c);
     } else {
         f32x4 bq[4], bk[4], bv[4];
-        issue_loads(aq, ak, av, 0);
-        if (nchunks > 1) issue_loads(bq, bk, bv, C);
+        issue_loads(aq, ak, av, c_begin * C);
+        if (c_begin + 1 < c_end) issue_loads(bq, bk, bv, (c_begin + 1) * C);
         __syncthreads();
-        for (int c = 0; c < nchunks; c += 2) {
+        for (int c = c_begin; c < c_end; c += 2) {
             chunk_body(aq, ak, av, c);
-            if (c + 1 < nchunks) chunk_body(bq, bk, bv, c + 1);
+            if (c + 1 < c_end) chunk_body(bq, bk, bv, c + 1);
         }
     }
 }
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 bool mfma_p1_supported(const fastmax_problem& p) {
     return p.p == 1 && p.causal && p.D == 64 && p.in_dtype == FASTMAX_F32 && p.out_dtype == FASTMAX_F32;
 }
-size_t mfma_p1_workspace(const fastmax_problem&) { return 0; }
+size_t mfma_p1_workspace(const fastmax_problem& p) { return split_workspace_bytes(p, 64); }
 
 template <int PF, int ST>
 static int launch_variant(const MfmaParams& prm, int nblocks, hipStream_t stream) {
@@ -312,8 +331,15 @@ int launch_fwd_mfma_p1(const FwdArgs& a) {
     // FASTMAX_MFMA_VARIANT = <prefetch distance 1|2><staged stores 0|1>, tuning knob for A/B runs
     const char* env = getenv("FASTMAX_MFMA_VARIANT");
     const int variant = env ? atoi(env) : 11;
-    MfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, reinterpret_cast<float*>(a.o), a.g, a.prob.H, a.prob.Nq, a.prob.a};
-    const int nb = a.prob.B * a.prob.H;
+    const SplitPlan plan = split_plan(a.prob);
+    if (plan.nseg > 1) {
+        if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, 64)) return FASTMAX_E_WORKSPACE;
+        const int rc = launch_split_states(a, plan, 64, nullptr);
+        if (rc) return rc;
+    }
+    MfmaParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, reinterpret_cast<float*>(a.o), a.g, a.prob.H, a.prob.Nq, a.prob.a,
+                   reinterpret_cast<const float*>(a.workspace), plan.nseg, plan.cps};
+    const int nb = a.prob.B * a.prob.H * plan.nseg;
     switch (variant) {
         case 10: return launch_variant<1, 0>(prm, nb, a.stream);
         case 20: return launch_variant<2, 0>(prm, nb, a.stream);

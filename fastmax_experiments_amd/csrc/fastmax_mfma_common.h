@@ -174,4 +174,69 @@ __device__ __forceinline__ void store_tile16(char* ost, const f32x4 (&acc)[DP / 
     }
 }
 
+// 16 bytes of input -> EPL floats
+template <typename TIN> __device__ __forceinline__ void piece_to_float(const u32x4 raw, float (&x)[InTraits<TIN>::EPL]) {
+    if constexpr (sizeof(TIN) == 4) {
+        const f32x4 f = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = f[i];
+    } else if constexpr (InTraits<TIN>::NP == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(raw[i] << 16);
+            x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+        }
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 hv = __builtin_bit_cast(h8, raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (float)hv[i];
+    }
+}
+
+// EPL floats -> bf16 part images (NPI parts) at (row, piece column c)
+template <int DP, int EPL, int NPI>
+__device__ __forceinline__ void stage_floats(char* smem, int base, int row, int c, const float (&x)[EPL]) {
+    constexpr int IMG = 64 * DP * 2;
+#pragma unroll
+    for (int hseg = 0; hseg < EPL / 4; ++hseg) {
+        const f32x4 v = {x[4 * hseg], x[4 * hseg + 1], x[4 * hseg + 2], x[4 * hseg + 3]};
+        const int e0 = c * EPL + 4 * hseg;                               // element column
+        const int off = img_off<DP>(row, e0 >> 3) + ((e0 & 7) << 1);
+        if constexpr (NPI == 2) {
+            bf16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
+            *reinterpret_cast<bf16x4*>(smem + base + IMG + off) = lo;
+        } else {
+            *reinterpret_cast<bf16x4*>(smem + base + off) = to_bf16x4(v);
+        }
+    }
+}
+
+// sum over the lanes that hold one staged row (COLS consecutive lanes, COLS in {8,16,32}); result valid in the
+// LAST lane of the group
+template <int COLS> __device__ __forceinline__ float rowgroup_sum(float v) {
+    if constexpr (COLS == 32) {
+        v = row16_sum_to_lane15(v);
+        // lane 15 / 31 of each 32-lane half hold the two halves: fold lane 15 into lane 31 (row_bcast15 semantics via shuffle)
+        const float lo = __shfl_up(v, 16, 64);
+        return v + lo;
+    } else if constexpr (COLS == 16) {
+        return row16_sum_to_lane15(v);
+    } else {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+        return v;
+    }
+}
+// broadcast of the group total back to every lane of the group (for the fused mean subtraction)
+template <int COLS> __device__ __forceinline__ float rowgroup_allsum(float v) {
+#pragma unroll
+    for (int off = 1; off < COLS; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
 }  // namespace fastmax

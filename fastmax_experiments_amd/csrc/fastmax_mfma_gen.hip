@@ -24,71 +24,9 @@ struct GenParams {
     const float *qscale, *kscale;     // (B*H) each or null: fused linearmax normalisation
     int H, N, D, out_dtype;
     float a;
+    const float* state;   // sequence split: inclusive prefix states [(bh*(nseg-1) + seg-1)][DP*DP + 2*DP], or null
+    int nseg, cps;
 };
-
-// 16 bytes of input -> EPL floats
-template <typename TIN> __device__ __forceinline__ void piece_to_float(const u32x4 raw, float (&x)[InTraits<TIN>::EPL]) {
-    if constexpr (sizeof(TIN) == 4) {
-        const f32x4 f = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = f[i];
-    } else if constexpr (InTraits<TIN>::NP == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[2 * i] = __uint_as_float(raw[i] << 16);
-            x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
-        }
-    } else {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        const h8 hv = __builtin_bit_cast(h8, raw);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = (float)hv[i];
-    }
-}
-
-// EPL floats -> bf16 part images (NPI parts) at (row, piece column c)
-template <int DP, int EPL, int NPI>
-__device__ __forceinline__ void stage_floats(char* smem, int base, int row, int c, const float (&x)[EPL]) {
-    constexpr int IMG = 64 * DP * 2;
-#pragma unroll
-    for (int hseg = 0; hseg < EPL / 4; ++hseg) {
-        const f32x4 v = {x[4 * hseg], x[4 * hseg + 1], x[4 * hseg + 2], x[4 * hseg + 3]};
-        const int e0 = c * EPL + 4 * hseg;                               // element column
-        const int off = img_off<DP>(row, e0 >> 3) + ((e0 & 7) << 1);
-        if constexpr (NPI == 2) {
-            bf16x4 hi, lo;
-            split4(v, hi, lo);
-            *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
-            *reinterpret_cast<bf16x4*>(smem + base + IMG + off) = lo;
-        } else {
-            *reinterpret_cast<bf16x4*>(smem + base + off) = to_bf16x4(v);
-        }
-    }
-}
-
-// sum over the lanes that hold one staged row (COLS consecutive lanes, COLS in {8,16,32}); result valid in the
-// LAST lane of the group
-template <int COLS> __device__ __forceinline__ float rowgroup_sum(float v) {
-    if constexpr (COLS == 32) {
-        v = row16_sum_to_lane15(v);
-        // lane 15 / 31 of each 32-lane half hold the two halves: fold lane 15 into lane 31 (row_bcast15 semantics via shuffle)
-        const float lo = __shfl_up(v, 16, 64);
-        return v + lo;
-    } else if constexpr (COLS == 16) {
-        return row16_sum_to_lane15(v);
-    } else {
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-        return v;
-    }
-}
-// broadcast of the group total back to every lane of the group (for the fused mean subtraction)
-template <int COLS> __device__ __forceinline__ float rowgroup_allsum(float v) {
-#pragma unroll
-    for (int off = 1; off < COLS; off <<= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 // grid = B*H, block = 256.  NORM: fused linearmax prologue on Q and K.
 template <int DP, typename TIN, bool NORM>
@@ -110,7 +48,8 @@ __global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg;
+    const int b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const float a = prm.a;
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
@@ -132,21 +71,48 @@ __global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
             rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
         }
     };
-    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
-    if (tid < DP) {
-        reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
-        reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
-    }
-    f32x4 s2acc[NSL][MT];                                       // S2[16mt + 4q4 + reg][16(w + 4sl) + r]
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) s2acc[sl][mt] = f32x4{0, 0, 0, 0};
-
     const int nchunks = (N + C - 1) / C;
-    issue(0);
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+    f32x4 s2acc[NSL][MT];                                       // S2[16mt + 4q4 + reg][16(w + 4sl) + r]
+    auto publish_s2 = [&]() {                                   // a * accumulators -> bf16 hi/lo image rows d
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x4 hi, lo;
+                split4(s2acc[sl][mt] * a, hi, lo);
+                const int off = img_off<DP>(16 * (w + 4 * sl) + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
+                *reinterpret_cast<bf16x4*>(smem + S2I + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + S2I + SIMG + off) = lo;
+            }
+    };
+    if (seg == 0) {
+        for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+        if (tid < DP) {
+            reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
+            reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) s2acc[sl][mt] = f32x4{0, 0, 0, 0};
+    } else {
+        const float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + (seg - 1)) * (DP * DP + 2 * DP);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s2acc[sl][mt][i] = rec[(16 * mt + 4 * q4 + i) * DP + 16 * (w + 4 * sl) + r];
+        publish_s2();
+        if (tid < DP) {
+            reinterpret_cast<float*>(smem + S1V)[DP * (c_begin & 1) + tid] = rec[DP * DP + tid];
+            reinterpret_cast<float*>(smem + KSUM)[DP * (c_begin & 1) + tid] = rec[DP * DP + DP + tid];
+        }
+    }
+    issue(c_begin * C);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         const int n0 = c * C, cur = c & 1, nxt = cur ^ 1;
         const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + DP * cur;
         const float* s1v_cur = reinterpret_cast<const float*>(smem + S1V) + DP * cur;
@@ -193,7 +159,7 @@ __global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
                 reinterpret_cast<float*>(smem + PARTV)[srow * DP + scol * EPL + e] = cv[e];
             }
         }
-        if (c + 1 < nchunks) issue(n0 + C);
+        if (c + 1 < c_end) issue(n0 + C);
         __syncthreads();                                             // B1
         for (int t = tid; t < 2 * DP; t += 256) {                    // running sums for the next chunk
             const int col = t % DP;
@@ -294,18 +260,7 @@ __global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
         // output rows through the (free) K/V image area: whole-row stores
         store_tile16<DP>(smem + KI + w * (16 * DP * 4), oacc, ginv, lane, prm.o, prm.out_dtype,
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
-        if (c + 1 < nchunks) {
-#pragma unroll
-            for (int sl = 0; sl < NSL; ++sl)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    bf16x4 hi, lo;
-                    split4(s2acc[sl][mt] * a, hi, lo);
-                    const int off = img_off<DP>(16 * (w + 4 * sl) + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
-                    *reinterpret_cast<bf16x4*>(smem + S2I + off) = hi;
-                    *reinterpret_cast<bf16x4*>(smem + S2I + SIMG + off) = lo;
-                }
-        }
+        if (c + 1 < c_end) publish_s2();
         // the K/V image area doubles as the output staging buffer: fence it before the next chunk's staging
         __syncthreads();
     }
@@ -351,9 +306,16 @@ bool mfma_gen_supported(const fastmax_problem& p, bool norm) {
 int launch_fwd_mfma_gen(const FwdArgs& a, const float* qscale, const float* kscale) {
     const bool norm = qscale != nullptr;
     if (!mfma_gen_supported(a.prob, norm)) return FASTMAX_E_BAD_SHAPE;
+    const SplitPlan plan = split_plan(a.prob);
+    const int dp = a.prob.D <= 64 ? 64 : 128;
+    if (plan.nseg > 1) {
+        if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, dp)) return FASTMAX_E_WORKSPACE;
+        const int rc = launch_split_states(a, plan, dp, kscale);
+        if (rc) return rc;
+    }
     GenParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, qscale, kscale, a.prob.H, a.prob.Nq, a.prob.D,
-                  a.prob.out_dtype, a.prob.a};
-    const int nb = a.prob.B * a.prob.H;
+                  a.prob.out_dtype, a.prob.a, reinterpret_cast<const float*>(a.workspace), plan.nseg, plan.cps};
+    const int nb = a.prob.B * a.prob.H * plan.nseg;
     switch (a.prob.in_dtype) {
         case FASTMAX_F32: return norm ? launch_gen_d<float, true>(prm, nb, a.stream) : launch_gen_d<float, false>(prm, nb, a.stream);
         case FASTMAX_BF16: return norm ? launch_gen_d<bf16_t, true>(prm, nb, a.stream) : launch_gen_d<bf16_t, false>(prm, nb, a.stream);

@@ -1,0 +1,197 @@
+// Sequence split for the linear-time fastmax kernels: when B*H workgroups cannot fill 256 CUs the
+// sequence of every head is cut into `nseg` segments that run as independent workgroups.
+//   1. p1_state_kernel     per (head, segment < nseg-1): local sums  S2 = sum k v^T, S1 = sum v, ksum = sum k
+//                          (the same K^T V MFMA step and exact fp32 column sums as the main kernel)
+//   2. p1_state_prefix     inclusive prefix of the records over the segments of a head (the causal
+//                          cumulative sum at segment granularity)
+//   3. the main kernel starts segment s from record s-1.
+// Cost: K and V of all but the last segment are read twice (+ <= 50 % of the K,V bytes, 0 when nseg = 1).
+#include "fastmax_mfma_common.h"
+
+namespace fastmax {
+
+struct StateParams {
+    const void *k, *v;
+    Strides3 ks, vs;
+    float* state;
+    const float* kscale;      // fused linearmax: K rows are (k - mean) * kscale[bh]
+    int H, N, D, nseg, cps;
+};
+
+template <int DP, typename TIN, bool NORM>
+__global__ __launch_bounds__(256) void p1_state_kernel(StateParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int C = 64, IMG = C * DP * 2;
+    constexpr int KI = 0, VI = NP * IMG, PARTV = 2 * NP * IMG;
+    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int PARTK = PARTV + RPP * DP * 4;
+    constexpr int MT = DP / 16, NSL = DP / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int seg = blockIdx.x, bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N, D = prm.D;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+    const bool colok = scol * EPL < D;
+    float ksc = 1.f;
+    if constexpr (NORM) ksc = prm.kscale[bh];
+    const float invD = 1.0f / (float)D;
+    const int nchunks = (N + C - 1) / C;
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+
+    u32x4 rk[NPASS], rv[NPASS];
+    auto issue = [&](int n0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = n0 + srow + ps * RPP;
+            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
+        }
+    };
+    f32x4 s2acc[NSL][MT];
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s2acc[sl][mt] = f32x4{0, 0, 0, 0};
+    float ck[EPL], cv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { ck[e] = 0.f; cv[e] = 0.f; }
+
+    issue(c_begin * C);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int n0 = c * C;
+        __syncthreads();                                           // previous chunk's images consumed
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = srow + ps * RPP;
+            float xk[EPL], xv[EPL];
+            piece_to_float<TIN>(rk[ps], xk);
+            piece_to_float<TIN>(rv[ps], xv);
+            if constexpr (NORM) {
+                float sk = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) sk += xk[e];
+                const float mk = rowgroup_allsum<COLS>(sk) * invD;
+                const bool live = colok && (n0 + row < N);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) xk[e] = live ? (xk[e] - mk) * ksc : 0.f;
+                stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
+            } else {
+                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+            }
+            stage_piece<DP, TIN>(smem, VI, row, scol, rv[ps]);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { ck[e] += xk[e]; cv[e] += xv[e]; }
+        }
+        if (c + 1 < c_end) issue(n0 + C);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) {
+                Frag<NP> vf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) vf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * (w + 4 * sl), lane);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    Frag<NP> kf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) kf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * mt, lane);
+                    s2acc[sl][mt] = mfma_parts<NP, NP>(kf, vf, s2acc[sl][mt]);
+                }
+            }
+        }
+    }
+    // record = [S2 (DP x DP, row-major [m][d]) | S1 (DP) | ksum (DP)]
+    float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg) * (DP * DP + 2 * DP);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        reinterpret_cast<float*>(smem + PARTK)[srow * DP + scol * EPL + e] = ck[e];
+        reinterpret_cast<float*>(smem + PARTV)[srow * DP + scol * EPL + e] = cv[e];
+    }
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rec[(16 * mt + 4 * q4 + i) * DP + 16 * (w + 4 * sl) + r] = s2acc[sl][mt][i];
+    __syncthreads();
+    for (int t = tid; t < 2 * DP; t += 256) {
+        const int col = t % DP;
+        const float* part = reinterpret_cast<const float*>(smem + (t < DP ? PARTV : PARTK));
+        float s = 0.f;
+        for (int g16 = 0; g16 < RPP; ++g16) s += part[g16 * DP + col];
+        rec[DP * DP + (t < DP ? 0 : DP) + col] = s;
+    }
+}
+
+// inclusive prefix over the nseg-1 records of one head; grid = (ceil(REC/256), B*H)
+__global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int nrec, int rec_floats) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rec_floats) return;
+    float* base = state + (int64_t)blockIdx.y * nrec * rec_floats + e;
+    float acc = 0.f;
+    for (int s = 0; s < nrec; ++s) {
+        acc += base[(int64_t)s * rec_floats];
+        base[(int64_t)s * rec_floats] = acc;
+    }
+}
+
+SplitPlan split_plan(const fastmax_problem& p) {
+    const int BH = p.B * p.H, nchunks = (p.Nq + 63) / 64;
+    if (BH >= 384 || nchunks < 8) return SplitPlan{1, nchunks};
+    int nseg = (512 + BH - 1) / BH;
+    if (nseg > nchunks / 4) nseg = nchunks / 4;                  // at least 4 chunks per segment
+    if (nseg > 32) nseg = 32;
+    if (nseg < 2) return SplitPlan{1, nchunks};
+    const int cps = (nchunks + nseg - 1) / nseg;
+    nseg = (nchunks + cps - 1) / cps;                            // drop empty trailing segments
+    return SplitPlan{nseg, cps};
+}
+
+size_t split_workspace_bytes(const fastmax_problem& p, int dp) {
+    const SplitPlan plan = split_plan(p);
+    if (plan.nseg <= 1) return 0;
+    return sizeof(float) * (size_t)p.B * p.H * (plan.nseg - 1) * ((size_t)dp * dp + 2 * dp);
+}
+
+template <int DP, typename TIN, bool NORM>
+static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
+    constexpr int lds = 2 * NP * 64 * DP * 2 + 2 * RPP * DP * 4;
+    auto kern = p1_state_kernel<DP, TIN, NORM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(256), lds, stream, prm);
+    const int rec = DP * DP + 2 * DP;
+    hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec);
+    return (int)hipGetLastError();
+}
+template <typename TIN, bool NORM>
+static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream) {
+    if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream);
+    if constexpr (InTraits<TIN>::NP == 2) return FASTMAX_E_BAD_SHAPE;
+    else return launch_state_t<128, TIN, NORM>(prm, BH, stream);
+}
+
+int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale) {
+    StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), kscale, a.prob.H, a.prob.Nq, a.prob.D,
+                    plan.nseg, plan.cps};
+    const int BH = a.prob.B * a.prob.H;
+    const bool norm = kscale != nullptr;
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return norm ? launch_state_d<float, true>(prm, BH, dp, a.stream) : launch_state_d<float, false>(prm, BH, dp, a.stream);
+        case FASTMAX_BF16: return norm ? launch_state_d<bf16_t, true>(prm, BH, dp, a.stream) : launch_state_d<bf16_t, false>(prm, BH, dp, a.stream);
+        case FASTMAX_F16: return norm ? launch_state_d<f16_t, true>(prm, BH, dp, a.stream) : launch_state_d<f16_t, false>(prm, BH, dp, a.stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

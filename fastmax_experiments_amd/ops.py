@@ -143,10 +143,11 @@ def linearmax_forward_fused(q, k, v):
     prob = _problem(q, k, q.dtype, q.dtype, 1, True, 1.0, 0.0)
     qi, ki = normalize_stats(q), normalize_stats(k)
     o = torch.empty((B, H, N, D), dtype=q.dtype, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_forward_workspace(ctypes.byref(prob)), dev)
     with torch.cuda.device(dev):
         rc = L.fastmax_hip_linearmax_forward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
                                              v.data_ptr(), _strides(v), qi.data_ptr(), ki.data_ptr(), o.data_ptr(), None,
-                                             _stream(dev))
+                                             wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
     if rc in (-2, -5):          # FASTMAX_E_BAD_SHAPE / _ALIGNMENT: not covered by the fused kernel
         return None
     _lib.check(rc, "fastmax_hip_linearmax_forward")

@@ -119,7 +119,9 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
                                   const void* k, const int64_t* k_strides,
                                   const void* v, const int64_t* v_strides,
                                   const float* q_inv_norm, const float* k_inv_norm,
-                                  void* o, float* g, void* stream);
+                                  void* o, float* g,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+/*      workspace of the fused call = fastmax_hip_forward_workspace(prob) (sequence-split states)   */
 
 /* ---- QLoRA linear: frozen NF4 base weight + LoRA branch, fused (csrc/nf4_lora.hip).
  *      Replaces the bitsandbytes Linear4bit matmul + the low-rank branch of

@@ -296,6 +296,26 @@ def test_linearmax_fused_prologue(shape, dt, tol):
     assert qq.grad is not None and qq.grad.dtype == dt and torch.isfinite(qq.grad).all()
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("shape", [(1, 2, 4096, 64), (1, 3, 1500, 64), (1, 1, 2048, 32), (1, 2, 2100, 128), (2, 8, 1024, 64)])
+def test_sequence_split_for_few_heads(shape, dt, tol):
+    """few heads -> the sequence is cut into segments (state kernel + prefix + main kernel): same result"""
+    from attention_mechanisms.fastmax import fastmax
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    from oracle import c_oracle, fastmax_oracle as orc
+    if shape[3] == 128 and dt == torch.float32:
+        pytest.skip("fp32 D=128 runs on the vector-ALU recurrent kernel")
+    g = torch.Generator().manual_seed(shape[2])
+    q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
+    o = fastmax(q.cuda(), k.cuda(), v.cuda())
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy())
+    assert rel_err(o.float().cpu().numpy(), ro) < tol
+    with torch.no_grad():
+        oh = fastmax_hack(q.cuda(), k.cuda(), v.cuda())
+    rh = orc.linearmax_fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), chunk=64)
+    assert rel_err(oh.float().cpu().numpy(), rh) < 2 * tol
+
+
 def test_cpu_tensors_round_trip_like_model_py():
     # lit_gpt/model.py:482-486 hands CPU tensors over and calls .cuda() on the result
     from attention_mechanisms.fastmax import fastmax

@@ -115,6 +115,8 @@ bool quad_mfma_supported(const fastmax_problem& p);
 int launch_bwd_quadratic(const BwdArgs& a);
 int launch_bwd_quad_mfma(const BwdArgs& a);
 bool quad_mfma_bwd_supported(const fastmax_problem& p);
+int launch_bwd_lin(const BwdArgs& a);
+bool lin_bwd_supported(const fastmax_problem& p);
 size_t bwd_quadratic_workspace(const fastmax_problem& p);
 int launch_normalize(const void* x, Strides3 xs, int dtype, float* y, float* inv_norm, int B, int H, int N, int D,
                      void* workspace, hipStream_t stream);

@@ -1,0 +1,456 @@
+// fastmax p=1 masked BACKWARD in linear time on the matrix cores (gfx950), D <= 64.
+//
+// Hand-derived gradients of attention_mechanisms/fastmax.py:432-485 (dQ: forward prefix sums),
+// 541-604 (dK) and 647-691 (dV: reverse cumulative sums) without the (N,D,D) temporaries.  With
+// w_i = 1/g_i, c_i = G_i.o_i, ghat_i = w_i G_i, e_i = -w_i c_i and T_ij = ghat_i.v_j + e_i (j <= i):
+//   dQ_i = a [ S2_i ghat_i + ksum_i e_i ]            S2_i = sum_{j<=i} k_j v_j^T,  ksum_i = sum_{j<=i} k_j
+//   dK_j = a [ R2_j v_j + rq_j ]                     R2_j = sum_{i>=j} q_i ghat_i^T, rq_j = sum_{i>=j} q_i e_i
+//   dV_j = R1_j + a R2_j^T k_j                       R1_j = sum_{i>=j} ghat_i
+// evaluated per 64-token chunk as (carried state) + (masked 64x64 tile), exactly like the forward kernel:
+//   bwd_p1_dq_kernel    walks the chunks forwards  (state S2 in MFMA accumulators, image [m][d] in LDS)
+//   bwd_p1_dkv_kernel   walks the chunks backwards (state R2 likewise; R1, rq exact fp32 vectors)
+// The dQ kernel also writes c_i to the workspace for the dK/dV kernel.
+#include "fastmax_mfma_common.h"
+
+namespace fastmax {
+
+struct LinBwdParams {
+    const void *q, *k, *v, *o, *go;
+    const float* g;
+    Strides3 qs, ks, vs, gos;
+    void *dq, *dk, *dv;
+    float* c;                       // workspace (B,H,N)
+    int H, N, D, grad_dtype, o_dtype;
+    float a;
+};
+
+template <int DP> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[DP / 16],
+                                                                  float scale, int row, int q4) {
+    // accumulators (rows = 16t + 4q4 + reg, column = `row` on the lane) -> bf16 hi/lo image row `row`
+#pragma unroll
+    for (int t = 0; t < DP / 16; ++t) {
+        bf16x4 hi, lo;
+        split4(acc[t] * scale, hi, lo);
+        const int off = img_off<DP>(row, 2 * t + (q4 >> 1)) + ((q4 & 1) << 3);
+        *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
+        *reinterpret_cast<bf16x4*>(smem + base + simg + off) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: grid = B*H, block = 256
+// ------------------------------------------------------------------------------------------------
+template <int DP, typename TIN>
+__global__ __launch_bounds__(256) void bwd_p1_dq_kernel(LinBwdParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
+    constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
+    constexpr int KSUM = S2I + 2 * SIMG;
+    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256;
+    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N, D = prm.D;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)h * prm.gos.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    // o is contiguous (B,H,N,D) in the input dtype on the masked path (dtype rule Q1)
+    const TIN* ob = reinterpret_cast<const TIN*>(prm.o) + (int64_t)bh * N * D;
+    u32x4 rk[NPASS], rv[NPASS], rg[NPASS], ro[NPASS];
+    float rw[NPASS];
+    auto issue = [&](int n0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = n0 + srow + ps * RPP;
+            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
+            rg[ps] = load_piece<TIN>(gb, prm.gos.sn, row, N, scol, D);
+            ro[ps] = load_piece<TIN>(ob, D, row, N, scol, D);
+            const int rc = row < N ? row : N - 1;
+            rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
+        }
+    };
+    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+    if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
+    f32x4 s2acc[DT];                                             // S2[m = 16w + r][d = 16dt + 4q4 + reg]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) s2acc[dt] = f32x4{0, 0, 0, 0};
+
+    const int nchunks = (N + C - 1) / C;
+    issue(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int n0 = c * C, cur = c & 1, nxt = cur ^ 1;
+        const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + DP * cur;
+        {
+            float ck[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) ck[e] = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = srow + ps * RPP;
+                float xk[EPL], xg[EPL], xo[EPL];
+                piece_to_float<TIN>(rk[ps], xk);
+                piece_to_float<TIN>(rg[ps], xg);
+                piece_to_float<TIN>(ro[ps], xo);
+                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                stage_piece<DP, TIN>(smem, VI, row, scol, rv[ps]);
+                stage_piece<DP, TIN>(smem, GI, row, scol, rg[ps]);
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { part = fmaf(xg[e], xo[e], part); ck[e] += xk[e]; }
+                part = rowgroup_sum<COLS>(part);                 // c_i = G_i . o_i
+                if (scol == COLS - 1) {
+                    reinterpret_cast<float*>(smem + CS)[row] = part;
+                    reinterpret_cast<float*>(smem + WS)[row] = rw[ps];
+                    if (n0 + row < N) prm.c[(int64_t)bh * N + n0 + row] = part;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) reinterpret_cast<float*>(smem + PARTK)[srow * DP + scol * EPL + e] = ck[e];
+        }
+        if (c + 1 < nchunks) issue(n0 + C);
+        __syncthreads();                                             // B1
+        if (tid < DP) {
+            float s = ksum_cur[tid];
+#pragma unroll 8
+            for (int g16 = 0; g16 < RPP; ++g16) s += reinterpret_cast<const float*>(smem + PARTK)[g16 * DP + tid];
+            reinterpret_cast<float*>(smem + KSUM)[DP * nxt + tid] = s;
+        }
+        // ---- phase A: dQ^T[m][i] for this wave's 16 queries ------------------------------------------
+        const int qi = 16 * w + r;
+        const float ci = reinterpret_cast<const float*>(smem + CS)[qi];
+        const float wi = reinterpret_cast<const float*>(smem + WS)[qi];
+        Frag<NP> gf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) gf[ks].p[p] = ld_row8<DP>(smem, GI + p * IMG, qi, 4 * ks + q4);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = *reinterpret_cast<const f32x4*>(ksum_cur + 16 * mt + 4 * q4) * (-ci);     // ksum_prev * (-c_i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<2> sf;
+                sf.p[0] = *reinterpret_cast<const bf16x8*>(smem + S2I + img_off<DP>(16 * mt + r, 4 * ks + q4));
+                sf.p[1] = *reinterpret_cast<const bf16x8*>(smem + S2I + SIMG + img_off<DP>(16 * mt + r, 4 * ks + q4));
+                acc[mt] = mfma_parts<2, NP>(sf, gf[ks], acc[mt]);                                  // S2_prev G_i
+            }
+        }
+        Frag<2> tf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 tt[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jt = 2 * s + e;
+                f32x4 u = {-ci, -ci, -ci, -ci};
+                if (jt <= w) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        Frag<NP> vf;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) vf.p[p] = ld_row8<DP>(smem, VI + p * IMG, 16 * jt + r, 4 * ks + q4);
+                        u = mfma_parts<NP, NP>(vf, gf[ks], u);                                     // v_j . G_i - c_i
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool keep = (jt < w) || (jt == w && (4 * q4 + i) <= r);
+                    tt[e][i] = keep ? u[i] : 0.f;
+                }
+            }
+            bf16x4 h0, l0, h1, l1;
+            split4(tt[0], h0, l0);
+            split4(tt[1], h1, l1);
+            tf[s].p[0] = cat4(h0, h1);
+            tf[s].p[1] = cat4(l0, l1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (2 * s <= w) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    Frag<NP> ktf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * mt, lane);
+                    acc[mt] = mfma_parts<NP, 2>(ktf, tf[s], acc[mt]);
+                }
+            }
+        }
+        // ---- phase B: S2[m = 16w + r][d] += sum_j K[j][m] V[j][d]  (rows d in registers) --------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frag<NP> kf;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) kf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * w, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                Frag<NP> vtf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) vtf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
+                s2acc[dt] = mfma_parts<NP, NP>(vtf, kf, s2acc[dt]);
+            }
+        }
+        __syncthreads();                                             // B2
+        store_tile16<DP>(smem + KI + w * (16 * DP * 4), acc, prm.a * wi, lane, prm.dq, prm.grad_dtype,
+                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        if (c + 1 < nchunks) publish_state<DP>(smem, S2I, SIMG, s2acc, 1.0f, 16 * w + r, q4);
+        __syncthreads();                                             // staging area (K/V/G images) free again
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
+// ------------------------------------------------------------------------------------------------
+template <int DP, typename TIN>
+__global__ __launch_bounds__(256) void bwd_p1_dkv_kernel(LinBwdParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
+    constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;
+    constexpr int R1 = R2I + 2 * SIMG, RQ = R1 + 2 * DP * 4;
+    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int PARTG = RQ + 2 * DP * 4, PARTQ = PARTG + RPP * DP * 4, ES = PARTQ + RPP * DP * 4;
+    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N, D = prm.D;
+    const float a = prm.a;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)h * prm.gos.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    u32x4 rq[NPASS], rk[NPASS], rv[NPASS], rg[NPASS];
+    float rw[NPASS], rc[NPASS];
+    auto issue = [&](int n0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = n0 + srow + ps * RPP;
+            rq[ps] = load_piece<TIN>(qb, prm.qs.sn, row, N, scol, D);
+            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
+            rg[ps] = load_piece<TIN>(gb, prm.gos.sn, row, N, scol, D);
+            const int rcl = row < N ? row : N - 1;
+            rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rcl] : 0.f;
+            rc[ps] = prm.c[(int64_t)bh * N + rcl];
+        }
+    };
+    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + R2I + 16 * i) = f32x4{0, 0, 0, 0};
+    if (tid < DP) {
+        reinterpret_cast<float*>(smem + R1)[tid] = 0.f;          // parity buffers are indexed by (chunk & 1)
+        reinterpret_cast<float*>(smem + R1)[DP + tid] = 0.f;
+        reinterpret_cast<float*>(smem + RQ)[tid] = 0.f;
+        reinterpret_cast<float*>(smem + RQ)[DP + tid] = 0.f;
+    }
+    f32x4 r2acc[DT];                                             // R2[m = 16w + r][d = 16dt + 4q4 + reg]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) r2acc[dt] = f32x4{0, 0, 0, 0};
+
+    const int nchunks = (N + C - 1) / C;
+    issue((nchunks - 1) * C);
+    __syncthreads();
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int n0 = c * C, cur = c & 1, nxt = cur ^ 1;
+        const float* r1_cur = reinterpret_cast<const float*>(smem + R1) + DP * cur;
+        const float* rq_cur = reinterpret_cast<const float*>(smem + RQ) + DP * cur;
+        {
+            float cg[EPL], cq[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { cg[e] = 0.f; cq[e] = 0.f; }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = srow + ps * RPP;
+                float xq[EPL], xg[EPL];
+                piece_to_float<TIN>(rq[ps], xq);
+                piece_to_float<TIN>(rg[ps], xg);
+                const float wi = rw[ps], ei = -wi * rc[ps];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { xg[e] *= wi; cg[e] += xg[e]; cq[e] = fmaf(xq[e], ei, cq[e]); }
+                stage_piece<DP, TIN>(smem, QI, row, scol, rq[ps]);
+                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                stage_piece<DP, TIN>(smem, VI, row, scol, rv[ps]);
+                stage_floats<DP, EPL, NP>(smem, GI, row, scol, xg);                  // ghat = w G
+                if (scol == 0) reinterpret_cast<float*>(smem + ES)[row] = ei;
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                reinterpret_cast<float*>(smem + PARTG)[srow * DP + scol * EPL + e] = cg[e];
+                reinterpret_cast<float*>(smem + PARTQ)[srow * DP + scol * EPL + e] = cq[e];
+            }
+        }
+        if (c > 0) issue(n0 - C);
+        __syncthreads();                                             // B1
+        for (int t = tid; t < 2 * DP; t += 256) {                    // suffix sums for the next (earlier) chunk
+            const int col = t % DP;
+            const bool isg = t < DP;
+            const float* part = reinterpret_cast<const float*>(smem + (isg ? PARTG : PARTQ));
+            float* base = reinterpret_cast<float*>(smem + (isg ? R1 : RQ));
+            float s = 0.f;
+#pragma unroll 8
+            for (int g16 = 0; g16 < RPP; ++g16) s += part[g16 * DP + col];
+            base[DP * nxt + col] = base[DP * cur + col] + (isg ? s : a * s);
+        }
+        // ---- phase A: this wave's 16 keys j = 16w + r ---------------------------------------------------
+        const int kj = 16 * w + r;
+        Frag<NP> kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                kf[ks].p[p] = ld_row8<DP>(smem, KI + p * IMG, kj, 4 * ks + q4);
+                vf[ks].p[p] = ld_row8<DP>(smem, VI + p * IMG, kj, 4 * ks + q4);
+            }
+        f32x4 dkacc[MT], dvacc[DT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            // dK^T[m][j] = rq'[m] + sum_d (a R2)[m][d] V[j][d]
+            dkacc[t] = *reinterpret_cast<const f32x4*>(rq_cur + 16 * t + 4 * q4);
+            // dV^T[d][j] = R1[d] + sum_m (a R2)[m][d] K[j][m]
+            dvacc[t] = *reinterpret_cast<const f32x4*>(r1_cur + 16 * t + 4 * q4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<2> rf, rtf;
+                rf.p[0] = *reinterpret_cast<const bf16x8*>(smem + R2I + img_off<DP>(16 * t + r, 4 * ks + q4));
+                rf.p[1] = *reinterpret_cast<const bf16x8*>(smem + R2I + SIMG + img_off<DP>(16 * t + r, 4 * ks + q4));
+                dkacc[t] = mfma_parts<2, NP>(rf, vf[ks], dkacc[t]);
+                rtf.p[0] = ld_tr8<DP>(smem, R2I, 32 * ks, 16 * t, lane);                   // A[row d][k = m], permuted k
+                rtf.p[1] = ld_tr8<DP>(smem, R2I + SIMG, 32 * ks, 16 * t, lane);
+                Frag<NP> kpf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) kpf.p[p] = ld_row8_perm<DP>(smem, KI + p * IMG, kj, 32 * ks, q4);
+                dvacc[t] = mfma_parts<2, NP>(rtf, kpf, dvacc[t]);
+            }
+        }
+        Frag<2> tf[2], pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 tt[2], pp[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int it = 2 * s + e;                            // 16 queries of the chunk
+                f32x4 u = *reinterpret_cast<const f32x4*>(smem + ES + (16 * it + 4 * q4) * 4);    // e_i per register row
+                f32x4 sc = {0, 0, 0, 0};
+                if (it >= w) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        Frag<NP> gf, qf;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            gf.p[p] = ld_row8<DP>(smem, GI + p * IMG, 16 * it + r, 4 * ks + q4);
+                            qf.p[p] = ld_row8<DP>(smem, QI + p * IMG, 16 * it + r, 4 * ks + q4);
+                        }
+                        u = mfma_parts<NP, NP>(gf, vf[ks], u);          // ghat_i . v_j + e_i
+                        sc = mfma_parts<NP, NP>(qf, kf[ks], sc);        // q_i . k_j
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool keep = (it > w) || (it == w && (4 * q4 + i) >= r);
+                    // rows past N carry w_i = 0 -> ghat = 0, e = 0, and P is multiplied by ghat rows (zero) below
+                    tt[e][i] = keep ? a * u[i] : 0.f;
+                    pp[e][i] = keep ? 1.0f + a * sc[i] : 0.f;
+                }
+            }
+            bf16x4 h0, l0, h1, l1;
+            split4(tt[0], h0, l0); split4(tt[1], h1, l1);
+            tf[s].p[0] = cat4(h0, h1); tf[s].p[1] = cat4(l0, l1);
+            split4(pp[0], h0, l0); split4(pp[1], h1, l1);
+            pf[s].p[0] = cat4(h0, h1); pf[s].p[1] = cat4(l0, l1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (2 * s + 1 >= w) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    Frag<NP> qtf, gtf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        qtf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * t, lane);
+                        gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * t, lane);
+                    }
+                    dkacc[t] = mfma_parts<NP, 2>(qtf, tf[s], dkacc[t]);      // += Q[i][m] a T_ij
+                    dvacc[t] = mfma_parts<NP, 2>(gtf, pf[s], dvacc[t]);      // += ghat[i][d] P_ij
+                }
+            }
+        }
+        // ---- phase B: R2[m = 16w + r][d] += sum_i Q[i][m] ghat[i][d] -------------------------------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frag<NP> qf;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * w, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                Frag<NP> gtf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * dt, lane);
+                r2acc[dt] = mfma_parts<NP, NP>(gtf, qf, r2acc[dt]);
+            }
+        }
+        __syncthreads();                                             // B2
+        store_tile16<DP>(smem + w * (16 * DP * 4), dkacc, 1.0f, lane, prm.dk, prm.grad_dtype,   // a is already folded in
+                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        store_tile16<DP>(smem + DP * 256 + w * (16 * DP * 4), dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
+                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        if (c > 0) publish_state<DP>(smem, R2I, SIMG, r2acc, a, 16 * w + r, q4);
+        __syncthreads();
+    }
+}
+
+template <int DP, typename TIN>
+static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
+    constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
+    constexpr int lds_q = 3 * NP * IMG + 2 * SIMG + 2 * DP * 4 + RPP * DP * 4 + 512;
+    constexpr int lds_kv = 4 * NP * IMG + 2 * SIMG + 4 * DP * 4 + 2 * RPP * DP * 4 + 256;
+    static_assert(lds_kv <= 160 * 1024, "LDS budget");
+    auto kq = bwd_p1_dq_kernel<DP, TIN>;
+    auto kkv = bwd_p1_dkv_kernel<DP, TIN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kq, dim3(BH), dim3(256), lds_q, stream, prm);
+    hipLaunchKernelGGL(kkv, dim3(BH), dim3(256), lds_kv, stream, prm);
+    return (int)hipGetLastError();
+}
+
+bool lin_bwd_supported(const fastmax_problem& p) {
+    if (!(p.p == 1 && p.causal) || p.D > 64) return false;
+    const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
+    // linear time pays off once the O(N^2) tiles outgrow the carried-state work
+    return (p.D % epl) == 0 && p.Nq >= 512;
+}
+
+int launch_bwd_lin(const BwdArgs& a) {
+    if (!lin_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;
+    LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
+                     reinterpret_cast<float*>(a.workspace), a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype,
+                     a.prob.out_dtype, a.prob.a};
+    const int BH = a.prob.B * a.prob.H;
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return launch_lin_bwd_t<64, float>(prm, BH, a.stream);
+        case FASTMAX_BF16: return launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream);
+        case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t>(prm, BH, a.stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

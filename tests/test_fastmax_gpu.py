@@ -316,6 +316,26 @@ def test_sequence_split_for_few_heads(shape, dt, tol):
     assert rel_err(oh.float().cpu().numpy(), rh) < 2 * tol
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_BWD), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("shape", [(2, 3, 640, 64), (1, 2, 1000, 32), (1, 2, 513, 48), (1, 1, 2048, 64)])
+def test_linear_time_backward(shape, dt, tol):
+    """p=1 masked backward by forward / reverse scans with carried state vs the C oracle and vs the tile kernels"""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2])
+    q, k, v, go = (torch.randn(shape, generator=g).to(dt) for _ in range(4))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=True, p=1)
+    grads = {}
+    for path in ("auto", "quadratic_mfma"):
+        _force(path)
+        qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = fastmax(qq, kk, vv)
+        o.backward(go.cuda())
+        grads[path] = [t.grad.float().cpu().numpy() for t in (qq, kk, vv)]
+        for gr, rr, n in zip(grads[path], e, ("dq", "dk", "dv")):
+            assert rel_err(gr, rr) < tol, (path, n)
+
+
 def test_cpu_tensors_round_trip_like_model_py():
     # lit_gpt/model.py:482-486 hands CPU tensors over and calls .cuda() on the result
     from attention_mechanisms.fastmax import fastmax

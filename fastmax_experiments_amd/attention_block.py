@@ -1,0 +1,93 @@
+"""The caller of the hot path, as a host for parity tests and the data-parallel fine-tune step.
+
+Reproduces the CALL CONTRACT of the reference's ``CausalSelfAttention.forward`` with LoRA / QLoRA layers
+(lit_gpt/model.py:380-458 with the ``attn_alg`` dispatch at 432-451, LoRA wiring lit_gpt/lora.py:565-604):
+    qkv = attn(x)                      LoRAQKVLinear (4-bit NF4 base when quantised)          model.py:392
+    view / permute / split / GQA expand / reshape to (B, n_head, T, head_size)               model.py:397-420
+    RoPE on the first rope_n_elem dims (apply_rope, model.py:702-708)                       model.py:422-425
+    y = fastmax(q,k,v,p=2,mask) | fastmax_hack(q,k,v,p=1,mask)  -- on the DEVICE tensors     model.py:460-487
+    y.reshape(B, T, head_size * n_head)   (no transpose on these branches: quirk Q3)        model.py:453-455
+    proj(y)                            LoRALinear                                            model.py:458
+It is deliberately NOT a port of lit-gpt's GPT: no config registry, KV cache, MLP or norms -- only the
+attention sub-layer that hands tensors to the operator.  Everything outside the two LoRA linears and the
+attention operator is stock tensor plumbing.
+"""
+import torch
+import torch.nn as nn
+
+from .attention_mechanisms.fastmax import fastmax
+from .attention_mechanisms.fastmax_hack import fastmax_hack
+from .lora import LoRALinear, LoRAQKVLinear
+
+
+def build_rope_cache(seq_len: int, n_elem: int, device=None, base: int = 10000, condense_ratio: int = 1):
+    """cos / sin tables of lit_gpt/model.py:676-699 (public RoPE formula)."""
+    theta = 1.0 / (base ** (torch.arange(0, n_elem, 2, device=device).float() / n_elem))
+    seq_idx = torch.arange(seq_len, device=device) / condense_ratio
+    idx_theta = torch.outer(seq_idx, theta).repeat(1, 2)
+    return torch.cos(idx_theta), torch.sin(idx_theta)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    half = x.size(-1) // 2
+    rotated = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+    return ((x * cos) + (rotated * sin)).to(dtype=x.dtype)
+
+
+class CausalSelfAttention(nn.Module):
+    def __init__(self, n_embd: int, n_head: int, n_query_groups: int = None, head_size: int = None, bias: bool = False,
+                 rotary_percentage: float = 1.0, attn_alg: str = "fastmax", r: int = 8, alpha: int = 16,
+                 dropout: float = 0.0, to_query: bool = True, to_key: bool = False, to_value: bool = True,
+                 to_projection: bool = False):
+        super().__init__()
+        self.n_head = n_head
+        self.n_query_groups = n_query_groups or n_head
+        self.head_size = head_size or n_embd // n_head
+        self.rope_n_elem = int(rotary_percentage * self.head_size)
+        if attn_alg not in ("fastmax", "linearmax"):
+            raise ValueError(f"Attention algorithm {attn_alg} not supported")          # model.py:450-451
+        self.attn_alg = attn_alg
+        shape = (n_head + 2 * self.n_query_groups) * self.head_size
+        self.attn = LoRAQKVLinear(n_embd, shape, n_head=n_head, n_query_groups=self.n_query_groups, r=r, lora_alpha=alpha,
+                                  lora_dropout=dropout, enable_lora=(to_query, to_key, to_value), bias=bias)
+        self.proj = LoRALinear(self.head_size * n_head, n_embd, r=(r if to_projection else 0), lora_alpha=alpha,
+                               lora_dropout=dropout, bias=bias)
+
+    def quantize_base(self):
+        """QLoRA: both frozen linears become 4-bit NF4 (what the bnb precision plugin does in the reference)."""
+        self.attn.quantize_base()
+        self.proj.quantize_base()
+        return self
+
+    def forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, input_pos=None) -> torch.Tensor:
+        B, T, C = x.size()
+        qkv = self.attn(x)
+        q_per_kv = self.n_head // self.n_query_groups
+        total_qkv = q_per_kv + 2
+        qkv = qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size).permute(0, 2, 3, 1, 4)
+        q, k, v = qkv.split((q_per_kv, 1, 1), dim=2)
+        if self.n_query_groups != self.n_head and (input_pos is None or self.n_query_groups != 1):
+            k = k.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
+            v = v.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
+        q = q.reshape(B, -1, T, self.head_size)
+        k = k.reshape(B, -1, T, self.head_size)
+        v = v.reshape(B, -1, T, self.head_size)
+        q_roped = apply_rope(q[..., :self.rope_n_elem], cos, sin)
+        k_roped = apply_rope(k[..., :self.rope_n_elem], cos, sin)
+        q = torch.cat((q_roped, q[..., self.rope_n_elem:]), dim=-1)
+        k = torch.cat((k_roped, k[..., self.rope_n_elem:]), dim=-1)
+        mask = input_pos is None                                   # model.py:462-466, 477-481
+        if self.attn_alg == "linearmax":
+            y = fastmax_hack(q, k, v, p=1, mask=mask)              # model.py:472
+        else:
+            y = fastmax(q, k, v, p=2, mask=mask)                   # model.py:485, minus the .cpu()/.cuda() hops
+        y = y.reshape(B, T, self.head_size * self.n_head)          # model.py:453-455 (no transpose: quirk Q3)
+        return self.proj(y)
+
+
+# head shapes of the BASELINE.json configs (lit_gpt/config.py:197-205, 1394-1411, 735-747)
+CONFIG_SHAPES = {
+    "pythia-14m": dict(n_embd=128, n_head=4, n_query_groups=4, head_size=32, rotary_percentage=0.25, bias=True),
+    "tiny-llama-1.1b": dict(n_embd=2048, n_head=32, n_query_groups=4, head_size=64, rotary_percentage=1.0, bias=False),
+    "Llama-2-7b-hf": dict(n_embd=4096, n_head=32, n_query_groups=32, head_size=128, rotary_percentage=1.0, bias=False),
+}

@@ -54,7 +54,7 @@ constexpr int LDS_BYTES = QK + 256;          // 75008
 // ------------------------------------------------------------------------------------------------
 // grid = B*H workgroups, block = 256 threads, dynamic LDS = m64::LDS_BYTES.  float32 I/O, D = 64.
 // ------------------------------------------------------------------------------------------------
-template <int PF, int ST>
+template <int PF, int ST, int SCHED>
 __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams prm) {
     using namespace m64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,9 +79,15 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t gn = n0 + srow + 16 * u;
-                rq[u] = *reinterpret_cast<const f32x4*>(qb + gn * prm.qs.sn + 4 * scol);
-                rk[u] = *reinterpret_cast<const f32x4*>(kb + gn * prm.ks.sn + 4 * scol);
-                rv[u] = *reinterpret_cast<const f32x4*>(vb + gn * prm.vs.sn + 4 * scol);
+                if constexpr (ST == 2) {                             // streamed once: non-temporal policy
+                    rq[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(qb + gn * prm.qs.sn + 4 * scol));
+                    rk[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kb + gn * prm.ks.sn + 4 * scol));
+                    rv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vb + gn * prm.vs.sn + 4 * scol));
+                } else {
+                    rq[u] = *reinterpret_cast<const f32x4*>(qb + gn * prm.qs.sn + 4 * scol);
+                    rk[u] = *reinterpret_cast<const f32x4*>(kb + gn * prm.ks.sn + 4 * scol);
+                    rv[u] = *reinterpret_cast<const f32x4*>(vb + gn * prm.vs.sn + 4 * scol);
+                }
             }
         } else {
 #pragma unroll
@@ -134,6 +140,19 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 
     auto chunk_body = [&](f32x4 (&rq)[4], f32x4 (&rk)[4], f32x4 (&rv)[4], int c) {
         const int n0 = c * C;
+        if constexpr (SCHED == 9) {
+            // ABLATION (timing only, wrong results): the kernel's HBM access pattern with no LDS / MFMA work
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gn = n0 + srow + 16 * u;
+                if (gn < N) {
+                    if constexpr (ST == 2) __builtin_nontemporal_store(rq[u] + rk[u] + rv[u], reinterpret_cast<f32x4*>(ob + (int64_t)gn * D + 4 * scol));
+                    else *reinterpret_cast<f32x4*>(ob + (int64_t)gn * D + 4 * scol) = rq[u] + rk[u] + rv[u];
+                }
+            }
+            if (c + PF < c_end) issue_loads(rq, rk, rv, n0 + PF * C);
+            return;
+        }
         const int cur = c & 1, nxt = cur ^ 1;
         const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + 64 * cur;
         const float* s1v_cur = reinterpret_cast<const float*>(smem + S1V) + 64 * cur;
@@ -180,8 +199,14 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             base[64 * nxt + col] = s;
         }
 
-        // ---- phase A: this wave's 16 queries --------------------------------------------------------
-        const int qi = 16 * w + r;                                   // query row inside the chunk
+        // ---- phase A: 16 queries per wave.  SCHED: the wave that takes the heavy (late) query tile rotates with
+        // the chunk, and every MFMA batch has its fragment loads issued one batch ahead (pinned by sched_barrier)
+        const int wq = SCHED ? ((w + c) & 3) : w;                    // query tile of this wave in this chunk
+        const int qi = 16 * wq + r;                                  // query row inside the chunk
+        f32x4 oacc[4];
+        float gsum = 0.f;
+        bf16x8 ph[2], pl[2];
+        if constexpr (SCHED == 0) {
         bf16x8 qh[2], ql[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -189,7 +214,6 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             ql[ks] = ld_row8<64>(smem, QL, qi, 4 * ks + q4);
         }
         // (3) inter-chunk: O^T = S1 + S2^T Q'^T      (A = S2^T image rows d, B = Q'^T)
-        f32x4 oacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             oacc[dt] = *reinterpret_cast<const f32x4*>(s1v_cur + 16 * dt + 4 * q4);
@@ -201,8 +225,6 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
             }
         }
         // (1) scores S^T[j][i] = k_j . q'_i for key tiles jt <= w; mask the diagonal tile; P = 1 + s
-        float gsum = 0.f;
-        bf16x8 ph[2], pl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 pt[2];
@@ -244,6 +266,100 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
                 }
             }
         }
+        } else {
+#define FM_SB() __builtin_amdgcn_sched_barrier(0)
+            bf16x8 qh[2], ql[2];
+            bf16x8 fa[2][2][2], fb[2][2][2];                         // two fragment batches: [tile][ks][hi/lo]
+            auto ld_rows = [&](bf16x8 (&f)[2][2][2], int baseh, int basel, int row0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        f[t][ks][0] = ld_row8<64>(smem, baseh, row0 + 16 * t + r, 4 * ks + q4);
+                        f[t][ks][1] = ld_row8<64>(smem, basel, row0 + 16 * t + r, 4 * ks + q4);
+                    }
+            };
+            auto mm_rows = [&](const bf16x8 (&f)[2][2][2], int t, f32x4 acc) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) acc = mfma3(f[t][ks][0], f[t][ks][1], qh[ks], ql[ks], acc);
+                return acc;
+            };
+            // L0: Q fragments, S2^T rows of d-tiles 0,1, S1 (accumulator init)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qh[ks] = ld_row8<64>(smem, QH, qi, 4 * ks + q4);
+                ql[ks] = ld_row8<64>(smem, QL, qi, 4 * ks + q4);
+            }
+            ld_rows(fa, S2H, S2L, 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = *reinterpret_cast<const f32x4*>(s1v_cur + 16 * dt + 4 * q4);
+            FM_SB();
+            ld_rows(fb, S2H, S2L, 32);                               // L1: d-tiles 2,3
+            FM_SB();
+            oacc[0] = mm_rows(fa, 0, oacc[0]);                       // (3) inter-chunk
+            oacc[1] = mm_rows(fa, 1, oacc[1]);
+            FM_SB();
+            ld_rows(fa, KH, KL, 0);                                  // L2: K rows of key tiles 0,1
+            FM_SB();
+            oacc[2] = mm_rows(fb, 0, oacc[2]);
+            oacc[3] = mm_rows(fb, 1, oacc[3]);
+            FM_SB();
+            ld_rows(fb, KH, KL, 32);                                 // L3: key tiles 2,3 (used when wq >= 2)
+            FM_SB();
+            // (1) scores for key tiles jt <= wq, masked diagonal, P = 1 + s, split hi/lo
+            f32x4 sc[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) sc[jt] = f32x4{0, 0, 0, 0};
+            sc[0] = mm_rows(fa, 0, sc[0]);
+            if (wq >= 1) sc[1] = mm_rows(fa, 1, sc[1]);
+            FM_SB();
+            bf16x8 va[4][2], vb[4][2];                               // V^T fragments [dt][hi/lo] for k-steps 0 / 1
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {                         // L4: V^T, keys 0..31
+                va[dt][0] = ld_tr8<64>(smem, VH, 0, 16 * dt, lane);
+                va[dt][1] = ld_tr8<64>(smem, VL, 0, 16 * dt, lane);
+            }
+            FM_SB();
+            if (wq >= 2) {
+                sc[2] = mm_rows(fb, 0, sc[2]);
+                if (wq >= 3) sc[3] = mm_rows(fb, 1, sc[3]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 pt[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int jt = 2 * s + e;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool keep = (jt < wq) || (jt == wq && (4 * q4 + i) <= r);
+                        const float sv = keep ? sc[jt][i] : 0.f;
+                        gsum += sv;
+                        pt[e][i] = keep ? 1.0f + sv : 0.f;
+                    }
+                }
+                bf16x4 h0, l0, h1, l1;
+                split4(pt[0], h0, l0);
+                split4(pt[1], h1, l1);
+                ph[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                pl[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            FM_SB();
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {                         // L5: V^T, keys 32..63
+                vb[dt][0] = ld_tr8<64>(smem, VH, 32, 16 * dt, lane);
+                vb[dt][1] = ld_tr8<64>(smem, VL, 32, 16 * dt, lane);
+            }
+            FM_SB();
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma3(va[dt][0], va[dt][1], ph[0], pl[0], oacc[dt]);   // (2) intra-chunk
+            FM_SB();
+            if (wq >= 2) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma3(vb[dt][0], vb[dt][1], ph[1], pl[1], oacc[dt]);
+            }
+            FM_SB();
+        }
         // denominator: count + q'.ksum_prev + intra-chunk score sum (over the 4 k-groups of the lane's query)
         gsum += __shfl_xor(gsum, 16, 64);
         gsum += __shfl_xor(gsum, 32, 64);
@@ -265,14 +381,18 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int rl = 4 * u + q4, c16 = r;                 // row inside the wave tile, 16-byte column
-                const f32x4 val = *reinterpret_cast<const f32x4*>(smem + ((c16 >> 3) ? QL : QH) + img_off<64>(16 * w + rl, c16 & 7));
-                const int go = n0 + 16 * w + rl;
-                if (go < N) *reinterpret_cast<f32x4*>(ob + (int64_t)go * D + 4 * c16) = val;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(smem + ((c16 >> 3) ? QL : QH) + img_off<64>(16 * wq + rl, c16 & 7));
+                const int go = n0 + 16 * wq + rl;
+                if (go < N) {
+                    if constexpr (ST == 2) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(ob + (int64_t)go * D + 4 * c16));
+                    else *reinterpret_cast<f32x4*>(ob + (int64_t)go * D + 4 * c16) = val;
+                }
             }
         }
         if (gi < N && gb && q4 == 0) gb[gi] = gval;
 
         // ---- phase B: S2[:, 16w..16w+15] += K^T V  (A = K^T, B = V, both by transposed reads) --------
+        if constexpr (SCHED == 0) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x8 vh = ld_tr8<64>(smem, VH, 32 * s, 16 * w, lane);
@@ -283,6 +403,32 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_mfma_d64_f32_kernel(MfmaParams 
                 const bf16x8 kl = ld_tr8<64>(smem, KL, 32 * s, 16 * mt, lane);
                 s2acc[mt] = mfma3(kh, kl, vh, vl, s2acc[mt]);
             }
+        }
+        } else {
+            bf16x8 kt0[4][2], kt1[4][2], vt0[2], vt1[2];
+            vt0[0] = ld_tr8<64>(smem, VH, 0, 16 * w, lane);
+            vt0[1] = ld_tr8<64>(smem, VL, 0, 16 * w, lane);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                kt0[mt][0] = ld_tr8<64>(smem, KH, 0, 16 * mt, lane);
+                kt0[mt][1] = ld_tr8<64>(smem, KL, 0, 16 * mt, lane);
+            }
+            FM_SB();
+            vt1[0] = ld_tr8<64>(smem, VH, 32, 16 * w, lane);
+            vt1[1] = ld_tr8<64>(smem, VL, 32, 16 * w, lane);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                kt1[mt][0] = ld_tr8<64>(smem, KH, 32, 16 * mt, lane);
+                kt1[mt][1] = ld_tr8<64>(smem, KL, 32, 16 * mt, lane);
+            }
+            FM_SB();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) s2acc[mt] = mfma3(kt0[mt][0], kt0[mt][1], vt0[0], vt0[1], s2acc[mt]);
+            FM_SB();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) s2acc[mt] = mfma3(kt1[mt][0], kt1[mt][1], vt1[0], vt1[1], s2acc[mt]);
+            FM_SB();
+#undef FM_SB
         }
         __syncthreads();                                             // B2: every read of this chunk's images is done
 
@@ -312,10 +458,10 @@ bool mfma_p1_supported(const fastmax_problem& p) {
 }
 size_t mfma_p1_workspace(const fastmax_problem& p) { return split_workspace_bytes(p, 64); }
 
-template <int PF, int ST>
+template <int PF, int ST, int SCHED>
 static int launch_variant(const MfmaParams& prm, int nblocks, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = fwd_p1_mfma_d64_f32_kernel<PF, ST>;
+    auto kern = fwd_p1_mfma_d64_f32_kernel<PF, ST, SCHED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            m64::LDS_BYTES);
@@ -330,7 +476,7 @@ int launch_fwd_mfma_p1(const FwdArgs& a) {
     if (!mfma_p1_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
     // FASTMAX_MFMA_VARIANT = <prefetch distance 1|2><staged stores 0|1>, tuning knob for A/B runs
     const char* env = getenv("FASTMAX_MFMA_VARIANT");
-    const int variant = env ? atoi(env) : 11;
+    const int variant = env ? atoi(env) : 121;
     const SplitPlan plan = split_plan(a.prob);
     if (plan.nseg > 1) {
         if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, 64)) return FASTMAX_E_WORKSPACE;
@@ -341,10 +487,13 @@ int launch_fwd_mfma_p1(const FwdArgs& a) {
                    reinterpret_cast<const float*>(a.workspace), plan.nseg, plan.cps};
     const int nb = a.prob.B * a.prob.H * plan.nseg;
     switch (variant) {
-        case 10: return launch_variant<1, 0>(prm, nb, a.stream);
-        case 20: return launch_variant<2, 0>(prm, nb, a.stream);
-        case 21: return launch_variant<2, 1>(prm, nb, a.stream);
-        default: return launch_variant<1, 1>(prm, nb, a.stream);
+        case 110: return launch_variant<1, 1, 0>(prm, nb, a.stream);     // <prefetch><staged stores><batched schedule>
+        case 210: return launch_variant<2, 1, 0>(prm, nb, a.stream);
+        case 129: return launch_variant<1, 2, 9>(prm, nb, a.stream);
+        case 119: return launch_variant<1, 1, 9>(prm, nb, a.stream);     // memory-pattern ablation (timing only)
+        case 219: return launch_variant<2, 1, 9>(prm, nb, a.stream);
+        case 111: return launch_variant<1, 1, 1>(prm, nb, a.stream);
+        default: return launch_variant<1, 2, 1>(prm, nb, a.stream);      // 121: batched schedule, staged non-temporal stores
     }
 }
 

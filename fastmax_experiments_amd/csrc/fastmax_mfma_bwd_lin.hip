@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void bwd_p1_dq_kernel(LinBwdParams prm) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
-            rg[ps] = load_piece<TIN>(gb, prm.gos.sn, row, N, scol, D);
-            ro[ps] = load_piece<TIN>(ob, D, row, N, scol, D);
+            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
+            rg[ps] = load_piece<TIN, true>(gb, prm.gos.sn, row, N, scol, D);
+            ro[ps] = load_piece<TIN, true>(ob, D, row, N, scol, D);
             const int rc = row < N ? row : N - 1;
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
         }
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(256) void bwd_p1_dkv_kernel(LinBwdParams prm) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
-            rq[ps] = load_piece<TIN>(qb, prm.qs.sn, row, N, scol, D);
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
-            rg[ps] = load_piece<TIN>(gb, prm.gos.sn, row, N, scol, D);
+            rq[ps] = load_piece<TIN, true>(qb, prm.qs.sn, row, N, scol, D);
+            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
+            rg[ps] = load_piece<TIN, true>(gb, prm.gos.sn, row, N, scol, D);
             const int rcl = row < N ? row : N - 1;
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rcl] : 0.f;
             rc[ps] = prm.c[(int64_t)bh * N + rcl];

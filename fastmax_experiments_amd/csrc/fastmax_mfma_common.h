@@ -102,13 +102,17 @@ template <> struct InTraits<bf16_t> { static constexpr int EPL = 8, NP = 1; };
 template <> struct InTraits<f16_t> { static constexpr int EPL = 8, NP = 2; };
 
 // one 16-byte load of row `row` (clamped) at element column c*EPL; zero outside the tensor
-template <typename TIN>
+// NT: non-temporal policy for tensors that are streamed exactly once (measured +5 % on the headline kernel)
+template <typename TIN, bool NT = false>
 __device__ __forceinline__ u32x4 load_piece(const TIN* base, int64_t sn, int row, int nrows, int c, int D) {
     constexpr int EPL = InTraits<TIN>::EPL;
     const bool ok = row < nrows && c * EPL < D;
     const int rr = row < nrows ? row : nrows - 1;
     const int cc = c * EPL < D ? c : 0;
-    u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)rr * sn + cc * EPL);
+    const u32x4* src = reinterpret_cast<const u32x4*>(base + (int64_t)rr * sn + cc * EPL);
+    u32x4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(src);
+    else v = *src;
     if (!ok) v = u32x4{0, 0, 0, 0};
     return v;
 }
@@ -141,14 +145,15 @@ __device__ __forceinline__ void stage_piece(char* smem, int base, int row, int c
 }
 
 __device__ __forceinline__ void store4_any(void* base, int dtype, int64_t idx, const f32x4 v) {
-    if (dtype == FASTMAX_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
-    else if (dtype == FASTMAX_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = to_bf16x4(v);
+    // outputs are written once and never re-read by the kernel: non-temporal stores
+    if (dtype == FASTMAX_F32) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx));
+    else if (dtype == FASTMAX_BF16) __builtin_nontemporal_store(to_bf16x4(v), reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx));
     else {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         h4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
-        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + idx) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + idx));
     }
 }
 

@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
-            rq[ps] = load_piece<TIN>(qb, prm.qs.sn, row, N, scol, D);
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
+            rq[ps] = load_piece<TIN, true>(qb, prm.qs.sn, row, N, scol, D);
+            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
+            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
         }
     };
     const int nchunks = (N + C - 1) / C;

@@ -14,6 +14,8 @@
 // are exact single parts.  Head sizes are padded to DP = 64 or 128 columns inside LDS only.
 #include "fastmax_mfma_common.h"
 
+#include <type_traits>
+
 namespace fastmax {
 
 struct QuadMfmaParams {
@@ -26,7 +28,7 @@ struct QuadMfmaParams {
 };
 
 // grid = (ceil(Nq/64), B*H), block = 256, dynamic LDS = 3*NP*64*DP*2 bytes
-template <int DP, int P, typename TIN>
+template <int DP, int P, typename TIN, int NPP>
 __global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int IMG = 64 * DP * 2;
@@ -79,17 +81,13 @@ __global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) 
     const int qidx = i0 + 16 * w + r;
     const float a = prm.a;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                                   // previous tile fully consumed
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
-            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
-        }
-        if (kt + 1 < nkt) issue(kt + 1);
-        __syncthreads();
+    // One key tile.  MASKED = the diagonal tile of a causal problem or a tile that runs past N_k: only those pay
+    // for the per-element compares.  NPP: parts of P (a bf16 problem with a bf16 result carries P as one rounded
+    // part: its rounding is of the size of the output rounding itself; everything else keeps hi + lo).
+    auto tile = [&](int kt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const bool diag = causal && kt == qt;
-        Frag<2> pf[2];
+        Frag<NPP> pf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 pt[2];
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) 
             for (int e = 0; e < 2; ++e) {
                 const int jt = 2 * s + e;
                 f32x4 sc = {0, 0, 0, 0};
-                if (!(diag && jt > w)) {                   // wave-uniform
+                if (!(MASKED && diag && jt > w)) {         // wave-uniform
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> kf;
@@ -108,31 +106,50 @@ __global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) 
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int key = kt * 64 + 16 * jt + 4 * q4 + i;
-                    const bool keep = key < Nk && (!causal || key <= qidx);
-                    const float pv = keep ? poly_f<P>(a * sc[i]) : 0.f;
+                    float pv = poly_f<P>(a * sc[i]);
+                    if constexpr (MASKED) {
+                        const int key = kt * 64 + 16 * jt + 4 * q4 + i;
+                        const bool keep = key < Nk && (!causal || key <= qidx);
+                        pv = keep ? pv : 0.f;
+                    }
                     gsum += pv;
                     pt[e][i] = pv;
                 }
             }
-            bf16x4 h0, l0, h1, l1;
-            split4(pt[0], h0, l0);
-            split4(pt[1], h1, l1);
-            pf[s].p[0] = cat4(h0, h1);
-            pf[s].p[1] = cat4(l0, l1);
+            if constexpr (NPP == 2) {
+                bf16x4 h0, l0, h1, l1;
+                split4(pt[0], h0, l0);
+                split4(pt[1], h1, l1);
+                pf[s].p[0] = cat4(h0, h1);
+                pf[s].p[1] = cat4(l0, l1);
+            } else {
+                pf[s].p[0] = cat4(to_bf16x4(pt[0]), to_bf16x4(pt[1]));
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (!(diag && 2 * s > w)) {                    // wave-uniform
+            if (!(MASKED && diag && 2 * s > w)) {          // wave-uniform
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     Frag<NP> vf;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) vf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
-                    oacc[dt] = mfma_parts<NP, 2>(vf, pf[s], oacc[dt]);
+                    oacc[dt] = mfma_parts<NP, NPP>(vf, pf[s], oacc[dt]);
                 }
             }
         }
+    };
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                   // previous tile fully consumed
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
+        }
+        if (kt + 1 < nkt) issue(kt + 1);
+        __syncthreads();
+        if ((causal && kt == qt) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
+        else tile(kt, std::false_type{});
     }
     gsum += __shfl_xor(gsum, 16, 64);
     gsum += __shfl_xor(gsum, 32, 64);
@@ -159,11 +176,11 @@ __global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) 
     }
 }
 
-template <int DP, int P, typename TIN>
-static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+template <int DP, int P, typename TIN, int NPP>
+static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     constexpr int lds = 3 * NP * 64 * DP * 2;
-    auto kern = fwd_quad_mfma_kernel<DP, P, TIN>;
+    auto kern = fwd_quad_mfma_kernel<DP, P, TIN, NPP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -173,6 +190,13 @@ static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {
     dim3 grid((prm.Nq + 63) / 64, B * prm.H), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, prm);
     return (int)hipGetLastError();
+}
+template <int DP, int P, typename TIN>
+static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+    if constexpr (InTraits<TIN>::NP == 1) {
+        if (prm.out_dtype != FASTMAX_F32) return launch_quad_n<DP, P, TIN, 1>(prm, B, stream);
+    }
+    return launch_quad_n<DP, P, TIN, 2>(prm, B, stream);
 }
 template <int P, typename TIN>
 static int launch_quad_d(const QuadMfmaParams& prm, int B, hipStream_t stream) {

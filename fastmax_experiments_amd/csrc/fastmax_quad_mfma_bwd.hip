@@ -8,6 +8,8 @@
 // result is bitwise reproducible.  Operand handling as in fastmax_quad_mfma.hip.
 #include "fastmax_mfma_common.h"
 
+#include <type_traits>
+
 namespace fastmax {
 
 struct QuadBwdParams {
@@ -98,17 +100,11 @@ __global__ __launch_bounds__(256) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
 #pragma unroll
     for (int mt = 0; mt < DT; ++mt) acc[mt] = f32x4{0, 0, 0, 0};
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
-            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
-        }
-        if (kt + 1 < nkt) issue(kt + 1);
-        __syncthreads();
+    constexpr int NPP = NP;                                  // parts of dS (one rounded part for bf16 problems)
+    auto tile = [&](int kt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const bool diag = causal && kt == qt;
-        Frag<2> df[2];
+        Frag<NPP> df[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 dt_[2];
@@ -116,7 +112,7 @@ __global__ __launch_bounds__(256) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
             for (int e = 0; e < 2; ++e) {
                 const int jt = 2 * s + e;
                 f32x4 u = {0, 0, 0, 0}, sc = {0, 0, 0, 0};
-                if (!(diag && jt > w)) {
+                if (!(MASKED && diag && jt > w)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> vf, kf;
@@ -131,30 +127,50 @@ __global__ __launch_bounds__(256) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int key = kt * 64 + 16 * jt + 4 * q4 + i;
-                    const bool keep = key < Nk && (!causal || key <= qidx);
                     const float fp = (P == 2) ? 1.0f + a * sc[i] : 1.0f;
-                    dt_[e][i] = keep ? (u[i] - ci) * wi * fp : 0.f;
+                    float dv_ = (u[i] - ci) * wi * fp;
+                    if constexpr (MASKED) {
+                        const int key = kt * 64 + 16 * jt + 4 * q4 + i;
+                        const bool keep = key < Nk && (!causal || key <= qidx);
+                        dv_ = keep ? dv_ : 0.f;
+                    }
+                    dt_[e][i] = dv_;
                 }
             }
-            bf16x4 h0, l0, h1, l1;
-            split4(dt_[0], h0, l0);
-            split4(dt_[1], h1, l1);
-            df[s].p[0] = cat4(h0, h1);
-            df[s].p[1] = cat4(l0, l1);
+            if constexpr (NPP == 2) {
+                bf16x4 h0, l0, h1, l1;
+                split4(dt_[0], h0, l0);
+                split4(dt_[1], h1, l1);
+                df[s].p[0] = cat4(h0, h1);
+                df[s].p[1] = cat4(l0, l1);
+            } else {
+                df[s].p[0] = cat4(to_bf16x4(dt_[0]), to_bf16x4(dt_[1]));
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (!(diag && 2 * s > w)) {
+            if (!(MASKED && diag && 2 * s > w)) {
 #pragma unroll
                 for (int mt = 0; mt < DT; ++mt) {
                     Frag<NP> ktf;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * mt, lane);
-                    acc[mt] = mfma_parts<NP, 2>(ktf, df[s], acc[mt]);           // dQ^T[m][i] += K[j][m] dS[j][i]
+                    acc[mt] = mfma_parts<NP, NPP>(ktf, df[s], acc[mt]);         // dQ^T[m][i] += K[j][m] dS[j][i]
                 }
             }
         }
+    };
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
+        }
+        if (kt + 1 < nkt) issue(kt + 1);
+        __syncthreads();
+        if ((causal && kt == qt) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
+        else tile(kt, std::false_type{});
     }
     __syncthreads();
     store_tile16<DP>(smem + KI + w * (16 * DP * 4), acc, a, lane, prm.dq, prm.grad_dtype,
@@ -212,21 +228,11 @@ __global__ __launch_bounds__(256) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) { dkacc[t] = f32x4{0, 0, 0, 0}; dvacc[t] = f32x4{0, 0, 0, 0}; }
 
-    for (int it = it0; it < nqt; ++it) {
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN>(smem, QI, srow + ps * RPP, scol, rq[ps]);
-            stage_piece<DP, TIN>(smem, GI, srow + ps * RPP, scol, rg[ps]);
-        }
-        if (tid < 64) {
-            reinterpret_cast<float*>(smem + WS)[tid] = rw;
-            reinterpret_cast<float*>(smem + CS)[tid] = rc;
-        }
-        if (it + 1 < nqt) issue(it + 1);
-        __syncthreads();
+    constexpr int NPP = NP;
+    auto tile = [&](int it, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const bool diag = causal && it == kt;
-        Frag<2> pwf[2], dsf[2];
+        Frag<NPP> pwf[2], dsf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 pw[2], ds[2];
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
             for (int e = 0; e < 2; ++e) {
                 const int itile = 2 * s + e;                 // 16 queries of the tile
                 f32x4 sc = {0, 0, 0, 0}, u = {0, 0, 0, 0};
-                if (!(diag && itile < w)) {                  // queries entirely before this wave's keys
+                if (!(MASKED && diag && itile < w)) {        // queries entirely before this wave's keys
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> qf, gf, kf, vf;
@@ -253,22 +259,33 @@ __global__ __launch_bounds__(256) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(smem + CS + (16 * itile + 4 * q4) * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int qi = it * 64 + 16 * itile + 4 * q4 + i;
-                    const bool keep = qi < Nq && kidx < Nk && (!causal || qi >= kidx);
                     const float sv = a * sc[i];
-                    pw[e][i] = keep ? poly_f<P>(sv) * w4[i] : 0.f;
-                    ds[e][i] = keep ? (u[i] - c4[i]) * w4[i] * poly_fprime<P>(sv) : 0.f;
+                    float pwv = poly_f<P>(sv) * w4[i];
+                    float dsv = (u[i] - c4[i]) * w4[i] * poly_fprime<P>(sv);
+                    if constexpr (MASKED) {
+                        const int qi = it * 64 + 16 * itile + 4 * q4 + i;
+                        const bool keep = qi < Nq && kidx < Nk && (!causal || qi >= kidx);
+                        pwv = keep ? pwv : 0.f;
+                        dsv = keep ? dsv : 0.f;
+                    }
+                    pw[e][i] = pwv;
+                    ds[e][i] = dsv;
                 }
             }
-            bf16x4 h0, l0, h1, l1;
-            split4(pw[0], h0, l0); split4(pw[1], h1, l1);
-            pwf[s].p[0] = cat4(h0, h1); pwf[s].p[1] = cat4(l0, l1);
-            split4(ds[0], h0, l0); split4(ds[1], h1, l1);
-            dsf[s].p[0] = cat4(h0, h1); dsf[s].p[1] = cat4(l0, l1);
+            if constexpr (NPP == 2) {
+                bf16x4 h0, l0, h1, l1;
+                split4(pw[0], h0, l0); split4(pw[1], h1, l1);
+                pwf[s].p[0] = cat4(h0, h1); pwf[s].p[1] = cat4(l0, l1);
+                split4(ds[0], h0, l0); split4(ds[1], h1, l1);
+                dsf[s].p[0] = cat4(h0, h1); dsf[s].p[1] = cat4(l0, l1);
+            } else {
+                pwf[s].p[0] = cat4(to_bf16x4(pw[0]), to_bf16x4(pw[1]));
+                dsf[s].p[0] = cat4(to_bf16x4(ds[0]), to_bf16x4(ds[1]));
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (!(diag && 2 * s + 1 < w)) {                  // both 16-query halves of the k-step before the keys
+            if (!(MASKED && diag && 2 * s + 1 < w)) {        // both 16-query halves of the k-step before the keys
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
                     Frag<NP> gtf, qtf;
@@ -277,11 +294,27 @@ __global__ __launch_bounds__(256) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
                         gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * t, lane);
                         qtf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * t, lane);
                     }
-                    dvacc[t] = mfma_parts<NP, 2>(gtf, pwf[s], dvacc[t]);        // dV^T[d][j] += G[i][d] P_ij w_i
-                    dkacc[t] = mfma_parts<NP, 2>(qtf, dsf[s], dkacc[t]);        // dK^T[m][j] += Q[i][m] dS_ij
+                    dvacc[t] = mfma_parts<NP, NPP>(gtf, pwf[s], dvacc[t]);      // dV^T[d][j] += G[i][d] P_ij w_i
+                    dkacc[t] = mfma_parts<NP, NPP>(qtf, dsf[s], dkacc[t]);      // dK^T[m][j] += Q[i][m] dS_ij
                 }
             }
         }
+    };
+    for (int it = it0; it < nqt; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN>(smem, QI, srow + ps * RPP, scol, rq[ps]);
+            stage_piece<DP, TIN>(smem, GI, srow + ps * RPP, scol, rg[ps]);
+        }
+        if (tid < 64) {
+            reinterpret_cast<float*>(smem + WS)[tid] = rw;
+            reinterpret_cast<float*>(smem + CS)[tid] = rc;
+        }
+        if (it + 1 < nqt) issue(it + 1);
+        __syncthreads();
+        if ((causal && it == kt) || (it + 1) * 64 > Nq || j0 + 64 > Nk) tile(it, std::true_type{});
+        else tile(it, std::false_type{});
     }
     __syncthreads();
     store_tile16<DP>(smem + w * (16 * DP * 4), dkacc, a, lane, prm.dk, prm.grad_dtype,

@@ -41,7 +41,7 @@ template <int DP> __device__ __forceinline__ void publish_state(char* smem, int 
 // dQ: grid = B*H, block = 256
 // ------------------------------------------------------------------------------------------------
 template <int DP, typename TIN>
-__global__ __launch_bounds__(256) void bwd_p1_dq_kernel(LinBwdParams prm) {
+__global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
     constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bwd_p1_dq_kernel(LinBwdParams prm) {
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 template <int DP, typename TIN>
-__global__ __launch_bounds__(256) void bwd_p1_dkv_kernel(LinBwdParams prm) {
+__global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;

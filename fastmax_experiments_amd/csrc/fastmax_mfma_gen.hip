@@ -30,7 +30,7 @@ struct GenParams {
 
 // grid = B*H, block = 256.  NORM: fused linearmax prologue on Q and K.
 template <int DP, typename TIN, bool NORM>
-__global__ __launch_bounds__(256) void fwd_p1_mfma_gen_kernel(GenParams prm) {
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_gen_kernel(GenParams prm) {
     // bf16 inputs stay single-part even when normalised in-kernel: the reference itself forms (q - mean)/max
     // in the input dtype (fastmax_hack.py:38-43), so rounding the normalised row to bf16 is its own precision
     constexpr int NP = InTraits<TIN>::NP;

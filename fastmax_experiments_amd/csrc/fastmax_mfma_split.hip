@@ -19,7 +19,7 @@ struct StateParams {
 };
 
 template <int DP, typename TIN, bool NORM>
-__global__ __launch_bounds__(256) void p1_state_kernel(StateParams prm) {
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StateParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2;
     constexpr int KI = 0, VI = NP * IMG, PARTV = 2 * NP * IMG;

@@ -29,7 +29,7 @@ struct QuadMfmaParams {
 
 // grid = (ceil(Nq/64), B*H), block = 256, dynamic LDS = 3*NP*64*DP*2 bytes
 template <int DP, int P, typename TIN, int NPP>
-__global__ __launch_bounds__(256) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
+__global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int IMG = 64 * DP * 2;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(QuadBwdParams prm) {
 
 // ---- dQ: grid = (ceil(Nq/64), B*H), block = 256, LDS = 4*NP*IMG ------------------------------------
 template <int DP, int P, typename TIN>
-__global__ __launch_bounds__(256) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
+__global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int IMG = 64 * DP * 2;
     constexpr int QI = 0, GI = NP * IMG, KI = 2 * NP * IMG, VI = 3 * NP * IMG;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
 
 // ---- dK, dV: grid = (ceil(Nk/64), B*H), block = 256, LDS = 4*NP*IMG + 512 --------------------------
 template <int DP, int P, typename TIN>
-__global__ __launch_bounds__(256) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_dkv_mfma_kernel(QuadBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int IMG = 64 * DP * 2;
     constexpr int QI = 0, GI = NP * IMG, KI = 2 * NP * IMG, VI = 3 * NP * IMG, WS = 4 * NP * IMG, CS = WS + 256;

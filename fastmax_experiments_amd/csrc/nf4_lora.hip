@@ -86,7 +86,7 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const f32x
 // forward: grid = (ceil(N/128), ceil(M/128)), block = 256.  Requires K % 64 == 0, N % 4 == 0.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void nf4_linear_fwd_kernel(Nf4Params prm) {
+__global__ __launch_bounds__(256, 2) void nf4_linear_fwd_kernel(Nf4Params prm) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128 + 64];
     char* Xs = smem;                      // [128 m][64 k] bf16, swizzled 128-byte rows
     char* Ws = smem + 128 * 128;          // [128 n][64 k]
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void nf4_linear_fwd_kernel(Nf4Params prm) {
 __device__ __forceinline__ int sw256(int row, int chunk) { return row * 256 + (((chunk ^ (2 * row)) & 15) << 4); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void nf4_linear_dx_kernel(Nf4Params prm) {
+__global__ __launch_bounds__(256, 2) void nf4_linear_dx_kernel(Nf4Params prm) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128 + 64];
     char* Gs = smem;                      // dy tile [128 m][64 n] bf16, 128-byte rows
     char* Ws = smem + 128 * 128;          // W tile  [64 n][128 k] bf16, 256-byte rows

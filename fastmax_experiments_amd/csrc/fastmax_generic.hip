@@ -480,40 +480,48 @@ int launch_bwd_quadratic(const BwdArgs& a) {
 // ------------------------------------------------------------------------------------------
 // linearmax prologue (fastmax.py:326-334): one wave per token
 // ------------------------------------------------------------------------------------------
-// max over tokens of the squared centred norm.  One block walks TOK tokens of one head: a token row is
-// spread over 16 lanes (DPP row reductions, 4 rows per wave at a time), the running max stays in registers
-// and each block issues ONE atomicMax (token-per-wave with an atomic each serialised on the head's word).
-template <typename T>
+// max over tokens of the squared centred norm.  One block walks TOK tokens of one head with 16-byte loads:
+// a token row is spread over LPR lanes (LPR = 32 covers D <= 128 in fp32, D <= 256 in 16-bit), the running max
+// stays in registers and each block issues ONE atomicMax (token-per-wave with an atomic each serialised on
+// the head's word).  Rows must be 16-byte aligned; `vec` = 0 selects the scalar-load form for unaligned views.
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_max_kernel(const void* x, Strides3 xs, int H, int N, int D,
-                                                            unsigned int* maxbits) {
-    constexpr int TOK = 1024;
+                                                            unsigned int* maxbits, int vec) {
+    constexpr int TOK = 256, EPL = 16 / sizeof(T), RPB = 256 / LPR;
     __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane & 15, rgrp = tid >> 4;                 // 16 lanes per row, 16 rows per block pass
+    const int sub = tid % LPR, rgrp = tid / LPR;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
     float best = 0.f;
-    for (int n = n_begin + rgrp; n < n_end; n += 16) {
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
-        float v[8];
+        float v[EPL];
+        if (vec) {
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            u4 raw = {0, 0, 0, 0};
+            if (sub * EPL < D) raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(row + sub * EPL));
+            const T* pv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = (sub * EPL + e) < D ? to_float(pv[e]) : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = (sub * EPL + e) < D ? to_float(row[sub * EPL + e]) : 0.f;
+        }
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = sub + 16 * e;
-            v[e] = d < D ? to_float(row[d]) : 0.f;
-            s += v[e];
-        }
+        for (int e = 0; e < EPL; ++e) s += v[e];
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+        for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
         const float mean = s / (float)D;
         float nn = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float c = (sub + 16 * e) < D ? v[e] - mean : 0.f;
+        for (int e = 0; e < EPL; ++e) {
+            const float c = (sub * EPL + e) < D ? v[e] - mean : 0.f;
             nn = fmaf(c, c, nn);
         }
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) nn += __shfl_xor(nn, off, 64);
+        for (int off = 1; off < LPR; off <<= 1) nn += __shfl_xor(nn, off, 64);
         best = fmaxf(best, nn);
     }
     best = wave_max(best);
@@ -541,6 +549,24 @@ __global__ __launch_bounds__(256) void normalize_apply_kernel(const void* x, Str
     if (lane + 64 < D) out[lane + 64] = (x1 - mean) * inv;
 }
 
+static int rows_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
+    const int epl = (int)(16 / es);
+    return (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((xs.sb * es) % 16 == 0) && ((xs.sh * es) % 16 == 0) &&
+           ((xs.sn * es) % 16 == 0) && (D % epl == 0);
+}
+
+// lanes per token row: the smallest power of two that covers D with 16-byte pieces (4..32)
+template <typename T>
+static void launch_max_lpr(const void* x, Strides3 xs, int B, int H, int N, int D, unsigned int* maxbits, hipStream_t stream) {
+    const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
+    const int vec = rows_vec_ok(x, xs, sizeof(T), D);
+    dim3 grid((N + 255) / 256, B * H), block(256);                 // TOK = 256 tokens per block
+    if (need <= 4) hipLaunchKernelGGL((normalize_max_kernel<T, 4>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
+    else if (need <= 8) hipLaunchKernelGGL((normalize_max_kernel<T, 8>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
+    else if (need <= 16) hipLaunchKernelGGL((normalize_max_kernel<T, 16>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
+    else hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
+}
+
 template <typename T>
 static int launch_normalize_t(const void* x, Strides3 xs, float* y, float* inv_norm, int B, int H, int N, int D,
                               void* ws, hipStream_t stream) {
@@ -548,7 +574,7 @@ static int launch_normalize_t(const void* x, Strides3 xs, float* y, float* inv_n
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid((N + 3) / 4, B * H), block(256);
-    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 1023) / 1024, B * H), block, 0, stream, x, xs, H, N, D, maxbits);
+    launch_max_lpr<T>(x, xs, B, H, N, D, maxbits, stream);
     hipLaunchKernelGGL((normalize_apply_kernel<T>), grid, block, 0, stream, x, xs, H, N, D, maxbits, y, inv_norm);
     return (int)hipGetLastError();
 }
@@ -562,7 +588,7 @@ static int launch_stats_t(const void* x, Strides3 xs, float* inv_norm, int B, in
     unsigned int* maxbits = reinterpret_cast<unsigned int*>(ws);
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((normalize_max_kernel<T>), dim3((N + 1023) / 1024, B * H), dim3(256), 0, stream, x, xs, H, N, D, maxbits);
+    launch_max_lpr<T>(x, xs, B, H, N, D, maxbits, stream);
     hipLaunchKernelGGL(normalize_finish_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, maxbits, inv_norm, B * H);
     return (int)hipGetLastError();
 }

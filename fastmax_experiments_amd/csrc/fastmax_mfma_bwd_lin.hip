@@ -199,11 +199,11 @@ __global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
                 s2acc[dt] = mfma_parts<NP, NP>(vtf, kf, s2acc[dt]);
             }
         }
+        // dQ rows, staged in the gradient dtype through this wave's own (already consumed) G image rows
+        store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
+                                              lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         __syncthreads();                                             // B2
-        store_tile16<DP>(smem + KI + w * (16 * DP * 4), acc, prm.a * wi, lane, prm.dq, prm.grad_dtype,
-                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         if (c + 1 < nchunks) publish_state<DP>(smem, S2I, SIMG, s2acc, 1.0f, 16 * w + r, q4);
-        __syncthreads();                                             // staging area (K/V/G images) free again
     }
 }
 

@@ -244,4 +244,57 @@ template <int COLS> __device__ __forceinline__ float rowgroup_allsum(float v) {
 }
 
 
+
+// Same, but staged in the OUTPUT dtype through a wave-private area, so no workgroup barrier is needed: the 16 image
+// rows a wave alone reads (its query rows) are free once their fragments sit in registers.  area0 / area1 are the
+// two 16-row blocks (2*DP bytes per row) of a two-part image; a 4-byte result row is split across them, a 2-byte
+// result row fits area0.  TOUT_BYTES = element size of the result.
+template <int DP, int TOUT_BYTES>
+__device__ __forceinline__ void store_tile16_private(char* area0, char* area1, const f32x4 (&acc)[DP / 16], float scale,
+                                                     int lane, void* out, int dtype, int64_t row0_elem, int first_row,
+                                                     int nrows, int D) {
+    constexpr int DT = DP / 16, NCH = DP / 8;                 // 16-byte chunks per area row
+    const int r = lane & 15, q4 = lane >> 4;
+    if constexpr (TOUT_BYTES == 4) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c16 = 4 * dt + q4, cc = c16 % NCH;
+            char* area = (c16 / NCH) ? area1 : area0;
+            *reinterpret_cast<f32x4*>(area + r * (2 * DP) + (((cc ^ r) & (NCH - 1)) << 4)) = acc[dt] * scale;
+        }
+#pragma unroll
+        for (int u = 0; u < (16 * (DP / 4)) / 64; ++u) {
+            const int idx = u * 64 + lane, rl = idx / (DP / 4), c16 = idx % (DP / 4), cc = c16 % NCH;
+            const char* area = (c16 / NCH) ? area1 : area0;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(area + rl * (2 * DP) + (((cc ^ rl) & (NCH - 1)) << 4));
+            if (first_row + rl < nrows && 4 * c16 < D)
+                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row0_elem + (int64_t)rl * D + 4 * c16));
+        }
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c8 = 4 * dt + q4;                        // 8-byte unit inside the row
+            char* dst = area0 + r * (2 * DP) + ((((c8 >> 1) ^ r) & (NCH - 1)) << 4) + ((c8 & 1) << 3);
+            const f32x4 v = acc[dt] * scale;
+            if (dtype == FASTMAX_BF16) *reinterpret_cast<bf16x4*>(dst) = to_bf16x4(v);
+            else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+                *reinterpret_cast<h4*>(dst) = o;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < (16 * NCH + 63) / 64; ++u) {
+            const int idx = u * 64 + lane, rl = idx / NCH, cc = idx % NCH;
+            if (idx < 16 * NCH) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(area0 + rl * (2 * DP) + (((cc ^ rl) & (NCH - 1)) << 4));
+                if (first_row + rl < nrows && 8 * cc < D)
+                    __builtin_nontemporal_store(val, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(out) + row0_elem + (int64_t)rl * D + 8 * cc));
+            }
+        }
+    }
+}
+
 }  // namespace fastmax

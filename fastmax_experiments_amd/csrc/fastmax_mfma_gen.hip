@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_gen_kernel(
         const float gval = (float)(gi + 1) + reinterpret_cast<const float*>(smem + QK)[qi] + gsum;
         const float ginv = 1.0f / gval;
         if (gi < N && prm.g && q4 == 0) prm.g[(int64_t)bh * N + gi] = gval;
+        // output rows, staged in the result dtype through this wave's own (already consumed) Q image rows
+        store_tile16_private<DP, sizeof(TIN)>(smem + QI + 16 * w * (2 * DP), smem + QI + IMG + 16 * w * (2 * DP), oacc, ginv,
+                                              lane, prm.o, prm.out_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         // ---- phase B: S2[:, 16(w+4sl) ..] += K^T V ------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -257,12 +260,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_gen_kernel(
             }
         }
         __syncthreads();                                             // B2: all reads of this chunk's images done
-        // output rows through the (free) K/V image area: whole-row stores
-        store_tile16<DP>(smem + KI + w * (16 * DP * 4), oacc, ginv, lane, prm.o, prm.out_dtype,
-                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         if (c + 1 < c_end) publish_s2();
-        // the K/V image area doubles as the output staging buffer: fence it before the next chunk's staging
-        __syncthreads();
     }
 }
 

@@ -18,6 +18,7 @@ E_BAD_P = -1
 SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_backward_workspace",
            "fastmax_hip_backward", "fastmax_hip_normalize_workspace", "fastmax_hip_normalize",
            "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string",
+           "fastmax_hip_decode_state_bytes", "fastmax_hip_p1_prefill_state", "fastmax_hip_p1_decode_step",
            "fastmax_hip_normalize_stats", "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
 
 
@@ -62,6 +63,12 @@ def lib():
     L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp, sz, vp]
     L.fastmax_hip_linearmax_forward.restype = ci
     i64 = ctypes.c_int64
+    L.fastmax_hip_decode_state_bytes.argtypes = [ci, ci, ci]
+    L.fastmax_hip_decode_state_bytes.restype = sz
+    L.fastmax_hip_p1_prefill_state.argtypes = [pp, vp, i64p, vp, i64p, fp, vp]
+    L.fastmax_hip_p1_prefill_state.restype = ci
+    L.fastmax_hip_p1_decode_step.argtypes = [vp, i64p, vp, i64p, vp, i64p, fp, vp, ci, ci, ci, ci, ci, ctypes.c_float, i64, vp]
+    L.fastmax_hip_p1_decode_step.restype = ci
     L.fastmax_hip_nf4_linear_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp]
     L.fastmax_hip_nf4_linear_forward.restype = ci
     L.fastmax_hip_nf4_linear_backward_input.argtypes = [vp, i64, vp, vp, vp, i64, ci, ci, ci, ci, vp]

@@ -114,6 +114,17 @@ class NF4Linear(nn.Module):
     def dequantize(self, dtype=torch.float32) -> torch.Tensor:
         return nf4_dequantize(self.weight.data, self.weight.quant_state[0], self.weight.quant_state[1], dtype)
 
+    # the block scales travel with the module state (state_dict round trips of a quantised model)
+    def get_extra_state(self):
+        qs = self.weight.quant_state
+        return {"absmax": qs[0].detach().cpu(), "shape": tuple(qs[1]), "blocksize": qs[3], "quant_type": qs[5]}
+
+    def set_extra_state(self, state):
+        qs = self.weight.quant_state
+        qs[0] = state["absmax"].to(self.weight.device)
+        qs[1] = torch.Size(state["shape"])
+        self.weight.quant_state = qs
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return qlora_linear(x, self, None, None)
 
@@ -346,3 +357,43 @@ def mark_only_lora_as_trainable(model: nn.Module) -> None:
 def lora_filter(key: str, value: Any) -> bool:
     """lit_gpt/lora.py:469-470."""
     return "lora_" in key
+
+
+def merge_lora_weights(model: nn.Module) -> None:
+    """lit_gpt/lora.py:473-477: merge every LoRA layer in place (4-bit bases: dequantise + add + requantise)."""
+    for module in model.modules():
+        if isinstance(module, LoRALinear):
+            module.merge()
+
+
+def save_lora_checkpoint(model: nn.Module, file_path) -> None:
+    """finetune/lora.py:341-343: only the adapter weights go to disk (`filter={"model": lora_filter}`)."""
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if lora_filter(k, v)}
+    torch.save({"model": sd}, str(file_path))
+
+
+def load_lora_checkpoint(model: nn.Module, file_path) -> None:
+    """scripts/merge_lora.py:70-73: adapter weights on top of the already-loaded base model (strict=False)."""
+    ckpt = torch.load(str(file_path), map_location="cpu", weights_only=True)
+    sd = ckpt.get("model", ckpt)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if unexpected:
+        raise KeyError(f"unexpected keys in LoRA checkpoint: {unexpected}")
+
+
+def merged_state_dict(model: nn.Module, dtype=None) -> dict:
+    """scripts/merge_lora.py:76-82: after merge_lora_weights, drop the LoRA parameters and the `linear.` level so the
+    result loads into the plain (non-LoRA) model; 4-bit bases are written dense."""
+    out = {}
+    for name, module in model.named_modules():
+        if isinstance(module, NF4Linear):
+            w = module.dequantize(dtype or module.weight.quant_state[2])
+            out[(name + ".weight").replace("linear.", "")] = w.detach().cpu()
+            if module.bias is not None:
+                out[(name + ".bias").replace("linear.", "")] = module.bias.detach().to(w.dtype).cpu()
+    quant_prefixes = tuple(n + "." for n, m in model.named_modules() if isinstance(m, NF4Linear))
+    for k, v in model.state_dict().items():
+        if lora_filter(k, v) or k.startswith(quant_prefixes) or k.endswith("_extra_state"):
+            continue
+        out[k.replace("linear.", "")] = v.detach().cpu()
+    return out

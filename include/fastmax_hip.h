@@ -123,6 +123,21 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
                                   void* workspace, size_t workspace_bytes, void* stream);
 /*      workspace of the fused call = fastmax_hip_forward_workspace(prob) (sequence-split states)   */
 
+/* ---- decode-time state cache (opt-in): O(D^2) per generated token instead of the reference's
+ *      unmasked recompute over the zero-padded KV cache (lit_gpt/model.py:427-430,464-466, generate/base.py:85-92).
+ *      state: per (b,h) record [S2 (DPxDP) | S1 (DP) | ksum (DP)] float32, DP = 64 (D <= 64) or 128.
+ *      prefill_state: state of a whole prompt (k, v: (B,H,N,D)); prob->p = 1, prob->causal = 1.
+ *      decode_step:   q,k,v of ONE new token ((B,H,1,D)); updates the state in place and writes
+ *                     o (B,H,1,D) = masked first-order fastmax at the new last position; count_after = number of
+ *                     tokens in the sequence including this one.  Not the reference's decode arithmetic (quirk Q4). */
+size_t fastmax_hip_decode_state_bytes(int B, int H, int D);
+int fastmax_hip_p1_prefill_state(const fastmax_problem* prob, const void* k, const int64_t* k_strides,
+                                 const void* v, const int64_t* v_strides, float* state, void* stream);
+int fastmax_hip_p1_decode_step(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                               const void* v, const int64_t* v_strides, float* state, void* o,
+                               int B, int H, int D, int in_dtype, int out_dtype, float a, int64_t count_after,
+                               void* stream);
+
 /* ---- QLoRA linear: frozen NF4 base weight + LoRA branch, fused (csrc/nf4_lora.hip).
  *      Replaces the bitsandbytes Linear4bit matmul + the low-rank branch of
  *      lit_gpt/lora.py:170-177 (LoRALinear.forward) and :398-433 (LoRAQKVLinear.forward):

@@ -420,3 +420,25 @@ def test_full_baseline_shape_properties():
     o4 = fastmax(q2, k2, v3)
     assert torch.equal(o4[:, :, :t], o[:, :, :t])
     assert not torch.equal(o4[:, :, t:], o[:, :, t:])
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,H,T,D", [(2, 3, 200, 64), (1, 2, 70, 32), (1, 2, 130, 128)])
+def test_decode_state_cache_matches_masked_forward(B, H, T, D, dt, tol):
+    """opt-in O(D^2)-per-token decode: prefill + 6 single-token steps == rows of the masked forward over T+6 tokens"""
+    from fastmax_experiments_amd.decode import FastmaxDecodeState
+    from oracle import c_oracle
+    if D == 128 and dt == torch.float32:
+        pytest.skip("fp32 D=128 state kernel not built")
+    g = torch.Generator().manual_seed(T)
+    q, k, v = (torch.randn(B, H, T + 6, D, generator=g).to(dt) for _ in range(3))
+    ref, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy())
+    st = FastmaxDecodeState(B, H, D, "cuda")
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    o = st.prefill(qc[:, :, :T], kc[:, :, :T], vc[:, :, :T])
+    assert rel_err(o.float().cpu().numpy(), ref[:, :, :T]) < tol
+    for t in range(T, T + 6):
+        ot = st.step(qc[:, :, t:t + 1], kc[:, :, t:t + 1], vc[:, :, t:t + 1])
+        assert ot.shape == (B, H, 1, D) and ot.dtype == dt
+        assert rel_err(ot.float().cpu().numpy(), ref[:, :, t:t + 1], atol=float(np.abs(ref).max())) < tol, t
+    assert st.count == T + 6

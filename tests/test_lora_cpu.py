@@ -129,3 +129,36 @@ def test_nf4linear_looks_like_a_bnb_weight():
     assert (q.dequantize() - lin.weight.data).abs().max() < 0.2 * lin.weight.data.abs().max()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         q(torch.randn(2, 128))
+
+
+def test_lora_only_checkpoint_and_merge_round_trip(tmp_path):
+    """finetune/lora.py:341-343 (adapter-only save) and scripts/merge_lora.py:70-82 (load on top, merge, strip)."""
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(lora.LoRALinear(16, 16, r=2, lora_alpha=4), lora.LoRAQKVLinear(16, 48, 4, 4, r=2, enable_lora=(True, False, True)))
+    for mod in m:
+        torch.nn.init.normal_(mod.lora_B)
+    path = tmp_path / "lit_model_lora_finetuned.pth"
+    lora.save_lora_checkpoint(m, path)
+    saved = torch.load(str(path), weights_only=True)["model"]
+    assert set(saved) == {"0.lora_A", "0.lora_B", "1.lora_A", "1.lora_B"}            # only lora_* keys
+    fresh = torch.nn.Sequential(lora.LoRALinear(16, 16, r=2, lora_alpha=4), lora.LoRAQKVLinear(16, 48, 4, 4, r=2, enable_lora=(True, False, True)))
+    fresh.load_state_dict({k: v for k, v in m.state_dict().items() if "lora_" not in k}, strict=False)
+    lora.load_lora_checkpoint(fresh, path)
+    x = torch.randn(3, 16)
+    assert torch.allclose(fresh(x), m(x), atol=1e-6)
+    lora.merge_lora_weights(fresh)
+    sd = lora.merged_state_dict(fresh)
+    assert set(sd) == {"0.weight", "0.bias", "1.weight", "1.bias"}
+    plain = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Linear(16, 48))
+    plain.load_state_dict(sd)
+    assert torch.allclose(plain(x), m(x), atol=1e-5)
+
+
+def test_nf4linear_state_dict_round_trip():
+    lin = torch.nn.Linear(128, 64)
+    q = lora.NF4Linear.from_linear(lin)
+    sd = q.state_dict()
+    assert "_extra_state" in sd and sd["weight"].dtype == torch.uint8
+    q2 = lora.NF4Linear(128, 64)
+    q2.load_state_dict(sd)
+    assert torch.equal(q2.dequantize(), q.dequantize())

@@ -27,12 +27,19 @@ struct QuadMfmaParams {
     float a, g0;
 };
 
-// grid = (ceil(Nq/64), B*H), block = 256, dynamic LDS = 3*NP*64*DP*2 bytes
+// QG = 16-query groups per wave: a workgroup covers 64*QG queries, so every K / V fragment read from LDS feeds QG
+// MFMAs and the per-tile barriers and staging are amortised over QG times the work.  Measured on MI355X (round 1):
+// QG = 2 costs more in occupancy (registers 117 -> 148..254, LDS +50 %) than the reuse returns at N = 4096
+// (p=2 bf16 2.23 -> 2.58 ms, fp32 5.47 -> 6.32 ms; only N = 2048 gained, 0.40 -> 0.36 ms), so QG = 1 ships.
+template <int DP, typename TIN, int NPP> constexpr int quad_qg() { return 1; }
+
+// grid = (ceil(Nq/(64 QG)), B*H), block = 256, dynamic LDS = (QG + 2) * NP * 64*DP*2 bytes
 template <int DP, int P, typename TIN, int NPP>
 __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
-    constexpr int IMG = 64 * DP * 2;
-    constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG;
+    constexpr int QG = quad_qg<DP, TIN, NPP>(), QT = 64 * QG;
+    constexpr int IMG = 64 * DP * 2, QIMG = QG * IMG;
+    constexpr int QI = 0, KI = NP * QIMG, VI = KI + NP * IMG;
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = 64 / RPP;
     constexpr int KS = DP / 32, DT = DP / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -44,17 +51,32 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
     const bool causal = prm.causal != 0;
     const int nqt = gridDim.x;
     const int qt = causal ? nqt - 1 - (int)blockIdx.x : (int)blockIdx.x;      // causal: heaviest query tiles first
-    const int i0 = qt * 64;
+    const int i0 = qt * QT;
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
     const int srow = tid / COLS, scol = tid % COLS;
 
-    // Q tile -> images (once)
+    // Q tile -> images (once); part p of the Q image lives at QI + p*QIMG
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
+    for (int ps = 0; ps < NPASS * QG; ++ps) {
         const int row = srow + ps * RPP;
-        stage_piece<DP, TIN>(smem, QI, row, scol, load_piece<TIN>(qb, prm.qs.sn, i0 + row, Nq, scol, D));
+        const u32x4 raw = load_piece<TIN>(qb, prm.qs.sn, i0 + row, Nq, scol, D);
+        if constexpr (NP == 1) {
+            *reinterpret_cast<u32x4*>(smem + QI + img_off<DP>(row, scol)) = raw;
+        } else {
+            float x[EPL];
+            piece_to_float<TIN>(raw, x);
+#pragma unroll
+            for (int hseg = 0; hseg < EPL / 4; ++hseg) {
+                const f32x4 v4 = {x[4 * hseg], x[4 * hseg + 1], x[4 * hseg + 2], x[4 * hseg + 3]};
+                bf16x4 hi, lo;
+                split4(v4, hi, lo);
+                const int e0 = scol * EPL + 4 * hseg, off = img_off<DP>(row, e0 >> 3) + ((e0 & 7) << 1);
+                *reinterpret_cast<bf16x4*>(smem + QI + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + QI + QIMG + off) = lo;
+            }
+        }
     }
     u32x4 rk[NPASS], rv[NPASS];
     auto issue = [&](int kt) {
@@ -65,76 +87,94 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
             rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, Nk, scol, D);
         }
     };
-    const int nkt = causal ? qt + 1 : (Nk + 63) / 64;
+    const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
     issue(0);
     __syncthreads();
-    Frag<NP> qf[KS];
+    Frag<NP> qf[QG][KS];
+    int qidx[QG];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int g = 0; g < QG; ++g) {
+        qidx[g] = i0 + 16 * (QG * w + g) + r;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) qf[ks].p[p] = ld_row8<DP>(smem, QI + p * IMG, 16 * w + r, 4 * ks + q4);
-
-    f32x4 oacc[DT];
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
-    float gsum = 0.f;
-    const int qidx = i0 + 16 * w + r;
+            for (int p = 0; p < NP; ++p) qf[g][ks].p[p] = ld_row8<DP>(smem, QI + p * QIMG, 16 * (QG * w + g) + r, 4 * ks + q4);
+    }
+    f32x4 oacc[QG][DT];
+    float gsum[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        gsum[g] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[g][dt] = f32x4{0, 0, 0, 0};
+    }
     const float a = prm.a;
 
-    // One key tile.  MASKED = the diagonal tile of a causal problem or a tile that runs past N_k: only those pay
-    // for the per-element compares.  NPP: parts of P (a bf16 problem with a bf16 result carries P as one rounded
-    // part: its rounding is of the size of the output rounding itself; everything else keeps hi + lo).
+    // One key tile.  MASKED = a tile that touches the causal diagonal or runs past N_k: only those pay for the
+    // per-element compares.  NPP: parts of P (a bf16 problem with a bf16 result carries P as one rounded part: its
+    // rounding is of the size of the output rounding itself; everything else keeps hi + lo).
     auto tile = [&](int kt, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const bool diag = causal && kt == qt;
-        Frag<NPP> pf[2];
+        Frag<NPP> pf[QG][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f32x4 pt[2];
+            f32x4 pt[QG][2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int jt = 2 * s + e;
-                f32x4 sc = {0, 0, 0, 0};
-                if (!(MASKED && diag && jt > w)) {         // wave-uniform
+                f32x4 sc[QG];
+#pragma unroll
+                for (int g = 0; g < QG; ++g) sc[g] = f32x4{0, 0, 0, 0};
+                // sub-tile entirely above the diagonal for every query group of this wave (wave-uniform)
+                const bool skip = MASKED && causal && (kt * 64 + 16 * jt) > (i0 + 16 * (QG * w + QG - 1) + 15);
+                if (!skip) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> kf;
 #pragma unroll
                         for (int p = 0; p < NP; ++p) kf.p[p] = ld_row8<DP>(smem, KI + p * IMG, 16 * jt + r, 4 * ks + q4);
-                        sc = mfma_parts<NP, NP>(kf, qf[ks], sc);
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) sc[g] = mfma_parts<NP, NP>(kf, qf[g][ks], sc[g]);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float pv = poly_f<P>(a * sc[i]);
-                    if constexpr (MASKED) {
-                        const int key = kt * 64 + 16 * jt + 4 * q4 + i;
-                        const bool keep = key < Nk && (!causal || key <= qidx);
-                        pv = keep ? pv : 0.f;
+                for (int g = 0; g < QG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float pv = poly_f<P>(a * sc[g][i]);
+                        if constexpr (MASKED) {
+                            const int key = kt * 64 + 16 * jt + 4 * q4 + i;
+                            const bool keep = key < Nk && (!causal || key <= qidx[g]);
+                            pv = keep ? pv : 0.f;
+                        }
+                        gsum[g] += pv;
+                        pt[g][e][i] = pv;
                     }
-                    gsum += pv;
-                    pt[e][i] = pv;
-                }
             }
-            if constexpr (NPP == 2) {
-                bf16x4 h0, l0, h1, l1;
-                split4(pt[0], h0, l0);
-                split4(pt[1], h1, l1);
-                pf[s].p[0] = cat4(h0, h1);
-                pf[s].p[1] = cat4(l0, l1);
-            } else {
-                pf[s].p[0] = cat4(to_bf16x4(pt[0]), to_bf16x4(pt[1]));
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                if constexpr (NPP == 2) {
+                    bf16x4 h0, l0, h1, l1;
+                    split4(pt[g][0], h0, l0);
+                    split4(pt[g][1], h1, l1);
+                    pf[g][s].p[0] = cat4(h0, h1);
+                    pf[g][s].p[1] = cat4(l0, l1);
+                } else {
+                    pf[g][s].p[0] = cat4(to_bf16x4(pt[g][0]), to_bf16x4(pt[g][1]));
+                }
             }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (!(MASKED && diag && 2 * s > w)) {          // wave-uniform
+            const bool skip = MASKED && causal && (kt * 64 + 32 * s) > (i0 + 16 * (QG * w + QG - 1) + 15);
+            if (!skip) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     Frag<NP> vf;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) vf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
-                    oacc[dt] = mfma_parts<NP, NPP>(vf, pf[s], oacc[dt]);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) oacc[g][dt] = mfma_parts<NP, NPP>(vf, pf[g][s], oacc[g][dt]);
                 }
             }
         }
@@ -148,38 +188,28 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
         }
         if (kt + 1 < nkt) issue(kt + 1);
         __syncthreads();
-        if ((causal && kt == qt) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
+        if ((causal && (kt + 1) * 64 > i0) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
         else tile(kt, std::false_type{});
     }
-    gsum += __shfl_xor(gsum, 16, 64);
-    gsum += __shfl_xor(gsum, 32, 64);
-    // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
-    const float gval = causal ? gsum : gsum - (float)Nk + prm.g0;
-    const float ginv = 1.0f / gval;
-    if (qidx < Nq && prm.g && q4 == 0) prm.g[(int64_t)bh * Nq + qidx] = gval;
-
-    // stage the wave's 16 x DP fp32 tile through the (now free) K/V image area -> whole-row stores
-    __syncthreads();
-    char* ost = smem + KI + w * (16 * DP * 4);
-    constexpr int C16 = DP / 4;                            // 16-byte chunks per staged row
+    __syncthreads();                                       // K / V images free: they become the output staging area
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int c16 = 4 * dt + q4;
-        *reinterpret_cast<f32x4*>(ost + r * (DP * 4) + (((c16 ^ r) & (C16 - 1)) << 4)) = oacc[dt] * ginv;
-    }
-#pragma unroll
-    for (int u = 0; u < (16 * C16) / 64; ++u) {
-        const int idx = u * 64 + lane, rl = idx / C16, c16 = idx % C16;
-        const f32x4 val = *reinterpret_cast<const f32x4*>(ost + rl * (DP * 4) + (((c16 ^ rl) & (C16 - 1)) << 4));
-        const int go = i0 + 16 * w + rl;
-        if (go < Nq && 4 * c16 < D) store4_any(prm.o, prm.out_dtype, ((int64_t)bh * Nq + go) * D + 4 * c16, val);
+    for (int g = 0; g < QG; ++g) {
+        float gs = gsum[g];
+        gs += __shfl_xor(gs, 16, 64);
+        gs += __shfl_xor(gs, 32, 64);
+        // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
+        const float gval = causal ? gs : gs - (float)Nk + prm.g0;
+        if (qidx[g] < Nq && prm.g && q4 == 0) prm.g[(int64_t)bh * Nq + qidx[g]] = gval;
+        const int row0 = i0 + 16 * (QG * w + g);
+        store_tile16<DP>(smem + KI + w * (16 * DP * 4), oacc[g], 1.0f / gval, lane, prm.o, prm.out_dtype,
+                         ((int64_t)bh * Nq + row0) * D, row0, Nq, D);
     }
 }
 
 template <int DP, int P, typename TIN, int NPP>
 static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
-    constexpr int NP = InTraits<TIN>::NP;
-    constexpr int lds = 3 * NP * 64 * DP * 2;
+    constexpr int NP = InTraits<TIN>::NP, QG = quad_qg<DP, TIN, NPP>();
+    constexpr int lds = (QG + 2) * NP * 64 * DP * 2;
     auto kern = fwd_quad_mfma_kernel<DP, P, TIN, NPP>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -187,7 +217,7 @@ static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((prm.Nq + 63) / 64, B * prm.H), block(256);
+    dim3 grid((prm.Nq + 64 * QG - 1) / (64 * QG), B * prm.H), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, prm);
     return (int)hipGetLastError();
 }

@@ -297,4 +297,34 @@ __device__ __forceinline__ void store_tile16_private(char* area0, char* area1, c
     }
 }
 
+
+// Walks 64-row tiles of one (b,h) slab of a (N, D) tensor with the staging map (row = srow + ps*RPP, piece scol):
+// interior tiles are plain pointer-increment loads (no clamps, no compares); only a tile that runs past the
+// tensor or a padded head size goes through load_piece.
+template <typename TIN, int NPASS, int RPP, bool NT = false>
+struct TileLoader {
+    const TIN* base;
+    int64_t sn;
+    int nrows, D, srow, scol;
+    bool full_cols;
+    __device__ __forceinline__ TileLoader(const TIN* b, int64_t sn_, int nrows_, int D_, int DP, int srow_, int scol_)
+        : base(b), sn(sn_), nrows(nrows_), D(D_), srow(srow_), scol(scol_), full_cols(D_ == DP) {}
+    __device__ __forceinline__ void load(int tile, u32x4 (&r)[NPASS]) const {
+        constexpr int EPL = InTraits<TIN>::EPL;
+        const int row0 = tile * 64;
+        if (full_cols && row0 + 64 <= nrows) {                       // block-uniform
+            const TIN* p = base + (int64_t)(row0 + srow) * sn + scol * EPL;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(p + (int64_t)ps * RPP * sn);
+                if constexpr (NT) r[ps] = __builtin_nontemporal_load(src);
+                else r[ps] = *src;
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) r[ps] = load_piece<TIN, NT>(base, sn, row0 + srow + ps * RPP, nrows, scol, D);
+        }
+    }
+};
+
 }  // namespace fastmax

@@ -79,13 +79,10 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
         }
     }
     u32x4 rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
     auto issue = [&](int kt) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = kt * 64 + srow + ps * RPP;
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, Nk, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, Nk, scol, D);
-        }
+        kload.load(kt, rk);
+        vload.load(kt, rv);
     };
     const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
     issue(0);

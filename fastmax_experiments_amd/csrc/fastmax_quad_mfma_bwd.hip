@@ -72,13 +72,10 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
         stage_piece<DP, TIN>(smem, GI, row, scol, load_piece<TIN>(gb, prm.gos.sn, i0 + row, Nq, scol, D));
     }
     u32x4 rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
     auto issue = [&](int kt) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = kt * 64 + srow + ps * RPP;
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, Nk, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, Nk, scol, D);
-        }
+        kload.load(kt, rk);
+        vload.load(kt, rv);
     };
     const int nkt = causal ? qt + 1 : (Nk + 63) / 64;
     issue(0);
@@ -207,13 +204,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_dkv_mfma_kernel(Qua
     }
     u32x4 rq[NPASS], rg[NPASS];
     float rw = 0.f, rc = 0.f;
+    const TileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, DP, srow, scol), gload(gb, prm.gos.sn, Nq, D, DP, srow, scol);
     auto issue = [&](int it) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = it * 64 + srow + ps * RPP;
-            rq[ps] = load_piece<TIN>(qb, prm.qs.sn, row, Nq, scol, D);
-            rg[ps] = load_piece<TIN>(gb, prm.gos.sn, row, Nq, scol, D);
-        }
+        qload.load(it, rq);
+        gload.load(it, rg);
         if (tid < 64) {
             const int gi = it * 64 + tid, gc = gi < Nq ? gi : Nq - 1;
             rw = 1.0f / prm.g[(int64_t)bh * Nq + gc];

@@ -10,6 +10,7 @@ int validate(const fastmax_problem* p) {
     if (p->B <= 0 || p->H <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->D <= 0 || p->D > FASTMAX_MAX_D)
         return FASTMAX_E_BAD_SHAPE;
     if (p->causal && p->Nq != p->Nk) return FASTMAX_E_BAD_SHAPE;
+    if ((int64_t)p->B * p->H > 65535) return FASTMAX_E_BAD_SHAPE;       // (b,h) rides on gridDim.y in the tile kernels
     if (p->in_dtype < 0 || p->in_dtype > 2 || p->out_dtype < 0 || p->out_dtype > 2) return FASTMAX_E_BAD_DTYPE;
     return FASTMAX_OK;
 }

@@ -64,14 +64,16 @@ __global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
     const TIN* ob = reinterpret_cast<const TIN*>(prm.o) + (int64_t)bh * N * D;
     u32x4 rk[NPASS], rv[NPASS], rg[NPASS], ro[NPASS];
     float rw[NPASS];
+    const TileLoader<TIN, NPASS, RPP, true> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol),
+        gload(gb, prm.gos.sn, N, D, DP, srow, scol), oload(ob, D, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
+        kload.load(n0 / C, rk);
+        vload.load(n0 / C, rv);
+        gload.load(n0 / C, rg);
+        oload.load(n0 / C, ro);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
-            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
-            rg[ps] = load_piece<TIN, true>(gb, prm.gos.sn, row, N, scol, D);
-            ro[ps] = load_piece<TIN, true>(ob, D, row, N, scol, D);
             const int rc = row < N ? row : N - 1;
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
         }
@@ -234,14 +236,16 @@ __global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dk
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS], rg[NPASS];
     float rw[NPASS], rc[NPASS];
+    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
+        vload(vb, prm.vs.sn, N, D, DP, srow, scol), gload(gb, prm.gos.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
+        qload.load(n0 / C, rq);
+        kload.load(n0 / C, rk);
+        vload.load(n0 / C, rv);
+        gload.load(n0 / C, rg);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
-            rq[ps] = load_piece<TIN, true>(qb, prm.qs.sn, row, N, scol, D);
-            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
-            rg[ps] = load_piece<TIN, true>(gb, prm.gos.sn, row, N, scol, D);
             const int rcl = row < N ? row : N - 1;
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rcl] : 0.f;
             rc[ps] = prm.c[(int64_t)bh * N + rcl];

@@ -62,14 +62,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_gen_kernel(
     const bool colok = scol * EPL < D;
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
+        vload(vb, prm.vs.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = n0 + srow + ps * RPP;
-            rq[ps] = load_piece<TIN, true>(qb, prm.qs.sn, row, N, scol, D);
-            rk[ps] = load_piece<TIN, true>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN, true>(vb, prm.vs.sn, row, N, scol, D);
-        }
+        qload.load(n0 / C, rq);
+        kload.load(n0 / C, rk);
+        vload.load(n0 / C, rv);
     };
     const int nchunks = (N + C - 1) / C;
     const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);

@@ -43,13 +43,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
     const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
 
     u32x4 rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = n0 + srow + ps * RPP;
-            rk[ps] = load_piece<TIN>(kb, prm.ks.sn, row, N, scol, D);
-            rv[ps] = load_piece<TIN>(vb, prm.vs.sn, row, N, scol, D);
-        }
+        kload.load(n0 / C, rk);
+        vload.load(n0 / C, rv);
     };
     f32x4 s2acc[NSL][MT];
 #pragma unroll

@@ -36,7 +36,7 @@ enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 enum fastmax_error {
     FASTMAX_OK = 0,
     FASTMAX_E_BAD_P = -1,        /* p not in {1,2}: the Python shim raises ValueError like fastmax.py:362,428 */
-    FASTMAX_E_BAD_SHAPE = -2,    /* non-positive size, causal with Nq != Nk, D > FASTMAX_MAX_D */
+    FASTMAX_E_BAD_SHAPE = -2,    /* non-positive size, causal with Nq != Nk, D > FASTMAX_MAX_D, B*H > 65535 */
     FASTMAX_E_BAD_DTYPE = -3,
     FASTMAX_E_WORKSPACE = -4,    /* workspace missing or too small */
     FASTMAX_E_ALIGNMENT = -5,    /* a base pointer or a stride breaks the 16-byte row alignment rule */

@@ -1,9 +1,18 @@
 // extern "C" entry points of libfastmax_hip.so (see include/fastmax_hip.h) + path selection.
 #include "fastmax_common.h"
 
+#include <cstdlib>
+
 using namespace fastmax;
 
 namespace {
+// bf16 problems take the all-MFMA kernel; FASTMAX_BF16_KERNEL=gen keeps the generic one (A/B runs)
+bool use_bf16_kernel(const fastmax_problem& p) {
+    // measured: D <= 64 gains 6 % (3 workgroups / CU), D = 128 loses 10 % (the extra tile + register pressure)
+    if (!mfma_bf16_supported(p) || p.D > 64) return false;
+    const char* e = getenv("FASTMAX_BF16_KERNEL");
+    return !(e && e[0] == 'g');
+}
 int validate(const fastmax_problem* p) {
     if (!p) return FASTMAX_E_NULL;
     if (p->p != 1 && p->p != 2) return FASTMAX_E_BAD_P;
@@ -84,7 +93,9 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
     switch (path) {
-        case FASTMAX_PATH_MFMA: return mfma_p1_supported(*prob) ? launch_fwd_mfma_p1(a) : launch_fwd_mfma_gen(a, nullptr, nullptr);
+        case FASTMAX_PATH_MFMA:
+            if (mfma_p1_supported(*prob)) return launch_fwd_mfma_p1(a);
+            return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, nullptr, nullptr) : launch_fwd_mfma_gen(a, nullptr, nullptr);
         case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
         case FASTMAX_PATH_QUADRATIC_MFMA: return launch_fwd_quad_mfma(a);
         default: return launch_fwd_quadratic(a);
@@ -153,7 +164,7 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
         return FASTMAX_E_ALIGNMENT;
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
-    return launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
+    return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, q_inv_norm, k_inv_norm) : launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }
 
 }  // extern "C"

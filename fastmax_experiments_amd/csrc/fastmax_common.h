@@ -102,6 +102,8 @@ int launch_fwd_mfma_p1(const FwdArgs& a);
 bool mfma_p1_supported(const fastmax_problem& p);
 size_t mfma_p1_workspace(const fastmax_problem& p);
 int launch_fwd_mfma_gen(const FwdArgs& a, const float* qscale, const float* kscale);
+int launch_fwd_mfma_bf16(const FwdArgs& a, const float* qscale, const float* kscale);
+bool mfma_bf16_supported(const fastmax_problem& p);
 bool mfma_gen_supported(const fastmax_problem& p, bool norm);
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
                            void* workspace, hipStream_t stream);

@@ -1,0 +1,270 @@
+// fastmax p=1 masked forward for bf16 tensors, linear in N -- every sum on the matrix cores.
+//
+// Same chunked scan as fastmax_mfma.hip / fastmax_mfma_gen.hip, specialised for exact single-part bf16 operands:
+// the "ones" terms that the fp32 kernels keep on the vector ALU ride on spare MFMA tiles here
+//     S1   = sum_j v_j      = (1^T V)      one extra A fragment of ones against the V fragments of step (4)
+//     ksum = sum_j k_j      = (K^T 1)      the K^T fragments of step (4) against a ones B fragment
+//     a q_i.ksum_prev                       one extra 16-row tile (row D = a*ksum) of the (a S2)^T image in step (3)
+// (products with 1.0 are exact, accumulation is fp32), so staging is a plain 16-byte copy global -> LDS, no per-chunk
+// partial-sum arrays exist and the workgroup needs 45 KB of LDS at D <= 64: three workgroups per CU.
+// NORM fuses the linearmax prologue (fastmax_hack.py:38-43) into staging as in the generic kernel.
+#include "fastmax_mfma_common.h"
+
+namespace fastmax {
+
+struct Bf16Params {
+    const void *q, *k, *v;
+    Strides3 qs, ks, vs;
+    void* o;
+    float* g;
+    const float *qscale, *kscale;
+    int H, N, D;
+    float a;
+    const float* state;
+    int nseg, cps;
+};
+
+template <int DP, bool NORM>
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_bf16_kernel(Bf16Params prm) {
+    using TIN = bf16_t;
+    constexpr int EPL = 8, C = 64, IMG = C * DP * 2, SIMG = (DP + 16) * DP * 2;
+    constexpr int QI = 0, KI = IMG, VI = 2 * IMG, S2I = 3 * IMG, S1V = S2I + 2 * SIMG;
+    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int KS = DP / 32, DT = DP / 16, MT = DP / 16, NSL = DP / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg;
+    const int b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N, D = prm.D;
+    const float a = prm.a;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
+    float qsc = 1.f, ksc = 1.f;
+    if constexpr (NORM) { qsc = prm.qscale[bh]; ksc = prm.kscale[bh]; }
+    const float invD = 1.0f / (float)D;
+    const int srow = tid / COLS, scol = tid % COLS;
+    const bool colok = scol * EPL < D;
+
+    u32x4 rq[NPASS], rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
+        vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    auto issue = [&](int c) {
+        qload.load(c, rq);
+        kload.load(c, rk);
+        vload.load(c, rv);
+    };
+    // A / B fragment of ones in row / column 0 (lanes r == 0), zeros elsewhere
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)(r == 0 ? 1.0f : 0.0f);
+
+    const int nchunks = (N + C - 1) / C;
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+    f32x4 s2acc[NSL][MT];          // S2[16mt + 4q4 + reg][16(w + 4sl) + r]
+    f32x4 s1acc[NSL];              // row 0 (q4 == 0, reg 0): S1[16(w + 4sl) + r]
+    f32x4 ksacc[NSL];              // column 0 (r == 0): ksum[16(w + 4sl) + 4q4 + reg]
+    auto publish = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x4 hi, lo;
+                split4(s2acc[sl][mt] * a, hi, lo);
+                const int off = img_off<DP>(16 * (w + 4 * sl) + r, 2 * mt + (q4 >> 1)) + ((q4 & 1) << 3);
+                *reinterpret_cast<bf16x4*>(smem + S2I + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + S2I + SIMG + off) = lo;
+            }
+            if (r == 0) {                                        // image row DP = a * ksum, columns m of tile w + 4sl
+                bf16x4 hi, lo;
+                split4(ksacc[sl] * a, hi, lo);
+                const int off = img_off<DP>(DP, 2 * (w + 4 * sl) + (q4 >> 1)) + ((q4 & 1) << 3);
+                *reinterpret_cast<bf16x4*>(smem + S2I + off) = hi;
+                *reinterpret_cast<bf16x4*>(smem + S2I + SIMG + off) = lo;
+            }
+            if (q4 == 0) reinterpret_cast<float*>(smem + S1V)[16 * (w + 4 * sl) + r] = s1acc[sl][0];
+        }
+    };
+    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+    if (tid < DP) reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+        s1acc[sl] = f32x4{0, 0, 0, 0};
+        ksacc[sl] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s2acc[sl][mt] = f32x4{0, 0, 0, 0};
+    }
+    if (seg > 0) {
+        __syncthreads();                                         // zero fill done before the partial overwrite
+        const float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + (seg - 1)) * (DP * DP + 2 * DP);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s2acc[sl][mt][i] = rec[(16 * mt + 4 * q4 + i) * DP + 16 * (w + 4 * sl) + r];
+            if (q4 == 0) s1acc[sl][0] = rec[DP * DP + 16 * (w + 4 * sl) + r];
+            if (r == 0)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ksacc[sl][i] = rec[DP * DP + DP + 16 * (w + 4 * sl) + 4 * q4 + i];
+        }
+        publish();
+    }
+    issue(c_begin);
+    __syncthreads();
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const int n0 = c * C;
+        // ---- (a) staging: plain copies (NORM: mean-centred and scaled Q, K rows) ----------------------------
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = srow + ps * RPP;
+            if constexpr (NORM) {
+                float xq[EPL], xk[EPL];
+                piece_to_float<TIN>(rq[ps], xq);
+                piece_to_float<TIN>(rk[ps], xk);
+                float sq = 0.f, sk = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { sq += xq[e]; sk += xk[e]; }
+                const float mq = rowgroup_allsum<COLS>(sq) * invD, mk = rowgroup_allsum<COLS>(sk) * invD;
+                const bool live = colok && (n0 + row < N);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    xq[e] = live ? (xq[e] - mq) * qsc : 0.f;
+                    xk[e] = live ? (xk[e] - mk) * ksc : 0.f;
+                }
+                stage_floats<DP, EPL, 1>(smem, QI, row, scol, xq);
+                stage_floats<DP, EPL, 1>(smem, KI, row, scol, xk);
+            } else {
+                *reinterpret_cast<u32x4*>(smem + QI + img_off<DP>(row, scol)) = rq[ps];
+                *reinterpret_cast<u32x4*>(smem + KI + img_off<DP>(row, scol)) = rk[ps];
+            }
+            *reinterpret_cast<u32x4*>(smem + VI + img_off<DP>(row, scol)) = rv[ps];
+        }
+        if (c + 1 < c_end) issue(c + 1);
+        __syncthreads();                                             // B1
+        // ---- phase A -----------------------------------------------------------------------------------------
+        const int qi = 16 * w + r;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = ld_row8<DP>(smem, QI, qi, 4 * ks + q4);
+        f32x4 oacc[DT];
+        f32x4 qkacc = {0, 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt <= DT; ++dt) {                           // tile DT is the (a ksum) row
+            f32x4 acc = {0, 0, 0, 0};
+            if (dt < DT) acc = *reinterpret_cast<const f32x4*>(smem + S1V + (16 * dt + 4 * q4) * 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 sh = *reinterpret_cast<const bf16x8*>(smem + S2I + img_off<DP>(16 * dt + r, 4 * ks + q4));
+                const bf16x8 sl_ = *reinterpret_cast<const bf16x8*>(smem + S2I + SIMG + img_off<DP>(16 * dt + r, 4 * ks + q4));
+                acc = mfma(sh, qf[ks], acc);
+                acc = mfma(sl_, qf[ks], acc);
+            }
+            if (dt < DT) oacc[dt < DT ? dt : 0] = acc;
+            else qkacc = acc;
+        }
+        const float qk = __shfl(qkacc[0], r, 64);                    // row 0 of the extra tile lives in lanes q4 == 0
+        float gsum = 0.f;
+        Frag<2> pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 pt[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jt = 2 * s + e;
+                f32x4 sc = {0, 0, 0, 0};
+                if (jt <= w) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) sc = mfma(ld_row8<DP>(smem, KI, 16 * jt + r, 4 * ks + q4), qf[ks], sc);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool keep = (jt < w) || (jt == w && (4 * q4 + i) <= r);
+                    const float sv = keep ? a * sc[i] : 0.f;
+                    gsum += sv;
+                    pt[e][i] = keep ? 1.0f + sv : 0.f;
+                }
+            }
+            bf16x4 h0, l0, h1, l1;
+            split4(pt[0], h0, l0);
+            split4(pt[1], h1, l1);
+            pf[s].p[0] = cat4(h0, h1);
+            pf[s].p[1] = cat4(l0, l1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (2 * s <= w) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = ld_tr8<DP>(smem, VI, 32 * s, 16 * dt, lane);
+                    oacc[dt] = mfma(vf, pf[s].p[0], oacc[dt]);
+                    oacc[dt] = mfma(vf, pf[s].p[1], oacc[dt]);
+                }
+            }
+        }
+        gsum += __shfl_xor(gsum, 16, 64);
+        gsum += __shfl_xor(gsum, 32, 64);
+        const int gi = n0 + qi;
+        const float gval = (float)(gi + 1) + qk + gsum;
+        if (gi < N && prm.g && q4 == 0) prm.g[(int64_t)bh * N + gi] = gval;
+        store_tile16_private<DP, 2>(smem + QI + 16 * w * (2 * DP), nullptr, oacc, 1.0f / gval, lane, prm.o, FASTMAX_BF16,
+                                    ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        // ---- phase B: S2 += K^T V, S1 += 1^T V, ksum += K^T 1 ------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) {
+                const bf16x8 vf = ld_tr8<DP>(smem, VI, 32 * s, 16 * (w + 4 * sl), lane);
+                s1acc[sl] = mfma(ones, vf, s1acc[sl]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 kf = ld_tr8<DP>(smem, KI, 32 * s, 16 * mt, lane);
+                    s2acc[sl][mt] = mfma(kf, vf, s2acc[sl][mt]);
+                    if (mt == w + 4 * sl) ksacc[sl] = mfma(kf, ones, ksacc[sl]);      // wave-uniform
+                }
+            }
+        }
+        __syncthreads();                                             // B2
+        if (c + 1 < c_end) publish();
+    }
+}
+
+template <int DP, bool NORM>
+static int launch_bf16_t(const Bf16Params& prm, int nb, hipStream_t stream) {
+    constexpr int lds = 3 * 64 * DP * 2 + 2 * (DP + 16) * DP * 2 + DP * 4;
+    auto kern = fwd_p1_mfma_bf16_kernel<DP, NORM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, stream, prm);
+    return (int)hipGetLastError();
+}
+
+bool mfma_bf16_supported(const fastmax_problem& p) {
+    return p.p == 1 && p.causal && p.in_dtype == FASTMAX_BF16 && p.out_dtype == FASTMAX_BF16 && (p.D % 8) == 0 && p.D <= 128;
+}
+
+int launch_fwd_mfma_bf16(const FwdArgs& a, const float* qscale, const float* kscale) {
+    if (!mfma_bf16_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    const SplitPlan plan = split_plan(a.prob);
+    const int dp = a.prob.D <= 64 ? 64 : 128;
+    if (plan.nseg > 1) {
+        if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, dp)) return FASTMAX_E_WORKSPACE;
+        const int rc = launch_split_states(a, plan, dp, kscale);
+        if (rc) return rc;
+    }
+    Bf16Params prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, qscale, kscale, a.prob.H, a.prob.Nq, a.prob.D, a.prob.a,
+                   reinterpret_cast<const float*>(a.workspace), plan.nseg, plan.cps};
+    const int nb = a.prob.B * a.prob.H * plan.nseg;
+    const bool norm = qscale != nullptr;
+    if (dp == 64) return norm ? launch_bf16_t<64, true>(prm, nb, a.stream) : launch_bf16_t<64, false>(prm, nb, a.stream);
+    return norm ? launch_bf16_t<128, true>(prm, nb, a.stream) : launch_bf16_t<128, false>(prm, nb, a.stream);
+}
+
+}  // namespace fastmax

@@ -442,3 +442,31 @@ def test_decode_state_cache_matches_masked_forward(B, H, T, D, dt, tol):
         assert ot.shape == (B, H, 1, D) and ot.dtype == dt
         assert rel_err(ot.float().cpu().numpy(), ref[:, :, t:t + 1], atol=float(np.abs(ref).max())) < tol, t
     assert st.count == T + 6
+
+
+def test_randomised_shapes_against_oracle():
+    """seeded sweep over shapes / dtypes / p / mask (ragged lengths, padded head sizes, few and many heads):
+    forward and backward through whatever kernel family the dispatcher picks, against the C oracle"""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    rng = np.random.default_rng(2024)
+    dts = [(torch.float32, TOL_FWD, TOL_BWD), (torch.bfloat16, 8e-3, 2.5e-2), (torch.float16, 2e-3, 5e-3)]
+    for trial in range(36):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        N = int(rng.choice([1, 3, 17, 63, 64, 65, 100, 191, 256, 333, 520, 777, 1100]))
+        D = int(rng.choice([8, 16, 24, 32, 40, 64, 72, 96, 128]))
+        p = int(rng.integers(1, 3))
+        mask = bool(rng.integers(0, 2)) or N < 2
+        dt, tf, tb = dts[trial % 3]
+        g = torch.Generator().manual_seed(1000 + trial)
+        q, k, v, go = (torch.randn(B, H, N, D, generator=g).to(dt) for _ in range(4))
+        qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = fastmax(qq, kk, vv, mask=mask, p=p)
+        ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=mask, p=p)
+        tag = (trial, B, H, N, D, p, mask, str(dt))
+        tol_f = tf if o.dtype != torch.float32 or dt == torch.float32 else TOL_FWD
+        assert rel_err(o.detach().float().cpu().numpy(), ro) < max(tf, tol_f), tag
+        o.backward(go.cuda().to(o.dtype))
+        e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
+        for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+            assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, tag + (n,)

@@ -8,8 +8,7 @@ using namespace fastmax;
 namespace {
 // bf16 problems take the all-MFMA kernel; FASTMAX_BF16_KERNEL=gen keeps the generic one (A/B runs)
 bool use_bf16_kernel(const fastmax_problem& p) {
-    // measured: D <= 64 gains 6 % (3 workgroups / CU), D = 128 loses 10 % (the extra tile + register pressure)
-    if (!mfma_bf16_supported(p) || p.D > 64) return false;
+    if (!mfma_bf16_supported(p)) return false;
     const char* e = getenv("FASTMAX_BF16_KERNEL");
     return !(e && e[0] == 'g');
 }

@@ -96,7 +96,7 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
             if (mfma_p1_supported(*prob)) return launch_fwd_mfma_p1(a);
             return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, nullptr, nullptr) : launch_fwd_mfma_gen(a, nullptr, nullptr);
         case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
-        case FASTMAX_PATH_QUADRATIC_MFMA: return launch_fwd_quad_mfma(a);
+        case FASTMAX_PATH_QUADRATIC_MFMA: return quad32_supported(a.prob) ? launch_fwd_quad32(a) : launch_fwd_quad_mfma(a);
         default: return launch_fwd_quadratic(a);
     }
 }

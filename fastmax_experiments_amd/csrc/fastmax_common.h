@@ -114,6 +114,8 @@ size_t split_workspace_bytes(const fastmax_problem& p, int dp);
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
 int launch_fwd_quad_mfma(const FwdArgs& a);
 bool quad_mfma_supported(const fastmax_problem& p);
+int launch_fwd_quad32(const FwdArgs& a);
+bool quad32_supported(const fastmax_problem& p);
 int launch_bwd_quadratic(const BwdArgs& a);
 int launch_bwd_quad_mfma(const BwdArgs& a);
 bool quad_mfma_bwd_supported(const fastmax_problem& p);

@@ -14,9 +14,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   DP = 128: 256-byte rows, chunk ^ 2*(row & 7)
 // Both are conflict-free for ds_read_b128 row reads (lane = row) and for ds_read_b64_tr_b16 blocks of
 // 4 rows x 16 columns taken at rows 4q+{0..3} / 16+4q+{0..3} (see tools/mfma_probe.hip).
-template <int DP> __device__ __forceinline__ int img_off(int row, int chunk) {
-    if constexpr (DP == 64) return row * 128 + (((chunk ^ row) & 7) << 4);
-    else return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+// 64-row bf16 tile images in LDS.
+// SW = 0: XOR swizzle for 16-row fragments (16x16x32 MFMA operands), dense rows.
+// SW = 1 / 2: padded rows for 32-row fragments (32x32x16 operands), no swizzle, so every fragment address is one lane
+// constant plus an immediate:
+//   1 (row reads, ds_read_b128): row stride 2 DP + 16 bytes -- the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
+//     of one chunk column land on 16 distinct 16-byte slots
+//   2 (transposed reads, ds_read_b64_tr_b16): row stride 2 DP + 64 bytes -- the 4 consecutive rows x 64 bytes of a
+//     half-wave land on the four 64-byte quarters of the 256-byte bank row
+template <int DP, int SW = 0> constexpr int img_row_bytes() { return SW == 0 ? 2 * DP : (SW == 1 ? 2 * DP + 16 : 2 * DP + 64); }
+template <int DP, int SW = 0> constexpr int img_bytes() { return 64 * img_row_bytes<DP, SW>(); }
+template <int DP, int SW = 0> __device__ __forceinline__ int img_off(int row, int chunk) {
+    if constexpr (SW == 0) {
+        if constexpr (DP == 64) return row * 128 + (((chunk ^ row) & 7) << 4);
+        else return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+    } else {
+        return row * img_row_bytes<DP, SW>() + (chunk << 4);
+    }
 }
 
 __device__ __forceinline__ void split4(const f32x4 x, bf16x4& hi, bf16x4& lo) {
@@ -36,8 +50,8 @@ __device__ __forceinline__ bf16x8 cat4(const bf16x4 a, const bf16x4 b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int DP> __device__ __forceinline__ bf16x8 ld_row8(const char* smem, int base, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(smem + base + img_off<DP>(row, chunk));
+template <int DP, int SW = 0> __device__ __forceinline__ bf16x8 ld_row8(const char* smem, int base, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(smem + base + img_off<DP, SW>(row, chunk));
 }
 
 // Row fragment in the PERMUTED k order (elements 0..3 = columns col0+4q.., 4..7 = col0+16+4q..): the
@@ -118,17 +132,17 @@ __device__ __forceinline__ u32x4 load_piece(const TIN* base, int64_t sn, int row
 }
 
 // write one staged piece into the bf16 image(s) of a tile; part p lives at base + p*IMG
-template <int DP, typename TIN>
+template <int DP, typename TIN, int SW = 0>
 __device__ __forceinline__ void stage_piece(char* smem, int base, int row, int c, const u32x4 raw) {
-    constexpr int IMG = 64 * DP * 2;
+    constexpr int IMG = img_bytes<DP, SW>();
     if constexpr (sizeof(TIN) == 4) {
         bf16x4 hi, lo;
         split4(__builtin_bit_cast(f32x4, raw), hi, lo);
-        const int off = img_off<DP>(row, c >> 1) + ((c & 1) << 3);
+        const int off = img_off<DP, SW>(row, c >> 1) + ((c & 1) << 3);
         *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
         *reinterpret_cast<bf16x4*>(smem + base + IMG + off) = lo;
     } else if constexpr (InTraits<TIN>::NP == 1) {
-        *reinterpret_cast<u32x4*>(smem + base + img_off<DP>(row, c)) = raw;
+        *reinterpret_cast<u32x4*>(smem + base + img_off<DP, SW>(row, c)) = raw;
     } else {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         const h8 hv = __builtin_bit_cast(h8, raw);
@@ -138,7 +152,7 @@ __device__ __forceinline__ void stage_piece(char* smem, int base, int row, int c
         bf16x4 h0, l0, h1, l1;
         split4(x0, h0, l0);
         split4(x1, h1, l1);
-        const int off = img_off<DP>(row, c);
+        const int off = img_off<DP, SW>(row, c);
         *reinterpret_cast<bf16x8*>(smem + base + off) = cat4(h0, h1);
         *reinterpret_cast<bf16x8*>(smem + base + IMG + off) = cat4(l0, l1);
     }

@@ -1,0 +1,369 @@
+// fastmax forward, quadratic evaluation, on 32x32x16 bf16 MFMA tiles (gfx950).
+//
+// Same function as fastmax_quad_mfma.hip (o_i = sum_j f(a q_i.k_j) v_j / g_i; reference: attention_mechanisms/fastmax.py:184-322,
+// both p, masked / unmasked, N_q != N_k); this is the throughput form for long sequences:
+//   * a wave owns 32 queries and NW waves (4 or 8) share every 64-key K / V tile, so one LDS fragment read (1 KiB)
+//     feeds a 32x32x16 MFMA (32 K MAC) instead of a 16x16x32 one (16 K MAC): half the LDS traffic per flop
+//   * Q fragments are loaded once from global memory straight into registers (no Q image)
+//   * K / V tiles are double-buffered in LDS; tile t+1 is written from registers right after the single barrier of
+//     tile t and tile t+2 is requested immediately (one barrier per tile, loads one full tile ahead)
+//   * S^T = K Q^T keeps the key on the accumulator row, so P = f(a S) in registers is already the B operand of
+//     O^T += V^T P^T; V^T fragments come from ds_read_b64_tr_b16 with the matching key order
+//   * f is two fused multiply-adds per element: 1 + s (a + s a^2/2)
+// 32x32x16 layouts (A: row = lane&31, k = 8(lane>>5)+j; B: col = lane&31, same k; C: col = lane&31,
+// row(i) = (i&3) + 8(i>>2) + 4(lane>>5)).
+#include "fastmax_mfma_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace fastmax {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Quad32Params {
+    const void *q, *k, *v;
+    Strides3 qs, ks, vs;
+    void* o;
+    float* g;
+    int H, BH, Nq, Nk, D, causal, out_dtype, nqt;
+    float a, g0;
+};
+
+__device__ __forceinline__ f32x16 mfma32(const bf16x8 a, const bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int NA, int NB>
+__device__ __forceinline__ f32x16 mfma32_parts(const Frag<NA>& a, const Frag<NB>& b, f32x16 c) {
+    c = mfma32(a.p[0], b.p[0], c);
+    if constexpr (NA == 2) c = mfma32(a.p[1], b.p[0], c);
+    if constexpr (NB == 2) c = mfma32(a.p[0], b.p[1], c);
+    return c;
+}
+
+// A operand of the 32x32x16 MFMA from a row-major image, transposed: lane (d = lane&31, h = lane>>5) receives
+// rows row0 + 4h + {0..3} and row0 + 8 + 4h + {0..3} of image column col0 + d  (= the key order of the accumulator
+// registers 8s..8s+7 of an S^T tile).
+template <int DP> __device__ __forceinline__ bf16x8 ld_tr8_32(const char* smem, int base, int row0, int col0, int lane) {
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int ra = row0 + 4 * (g >> 1) + qq, rb = ra + 8;
+    const int col = col0 + 16 * (g & 1) + 4 * pp;
+    const int chunk = col >> 3, half = (col & 4) << 1;
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP, 2>(ra, chunk) + half));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP, 2>(rb, chunk) + half));
+    return u.v;
+}
+
+// 8 consecutive elements (columns col0..col0+7) of one query row -> B fragment part(s); zero outside the tensor
+template <typename TIN>
+__device__ __forceinline__ Frag<InTraits<TIN>::NP> load_q_frag(const TIN* base, int64_t sn, int row, int nrows, int col0, int D) {
+    constexpr int EPL = InTraits<TIN>::EPL, NP = InTraits<TIN>::NP;
+    Frag<NP> f;
+    if constexpr (NP == 1) {
+        f.p[0] = __builtin_bit_cast(bf16x8, load_piece<TIN>(base, sn, row, nrows, col0 / EPL, D));
+    } else {
+        float x[8];
+        if constexpr (EPL == 4) {
+            float lo4[4], hi4[4];
+            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4, D), lo4);
+            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4 + 1, D), hi4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = lo4[i]; x[4 + i] = hi4[i]; }
+        } else {
+            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 8, D), x);
+        }
+        bf16x4 h0, l0, h1, l1;
+        split4(f32x4{x[0], x[1], x[2], x[3]}, h0, l0);
+        split4(f32x4{x[4], x[5], x[6], x[7]}, h1, l1);
+        f.p[0] = cat4(h0, h1);
+        f.p[1] = cat4(l0, l1);
+    }
+    return f;
+}
+
+template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks() {
+    // bf16 D<=64 with a 16-bit result needs ~166 registers: three 4-wave workgroups per CU; everything else two waves / SIMD
+    if (DP == 64 && InTraits<TIN>::NP == 1 && NPP == 1) return NW == 8 ? 1 : 3;
+    return NW == 8 ? 1 : 2;
+}
+
+// 1-D grid of nqt * BH workgroups; block = 64 NW threads; dynamic LDS = max(2 stages of K,V images, NW * 4 KiB)
+template <int DP, int P, typename TIN, int NPP, int NW>
+__global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) void fwd_quad32_kernel(Quad32Params prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int NT = 64 * NW, QT = 32 * NW;
+    constexpr int KIMG = img_bytes<DP, 1>(), VIMG = img_bytes<DP, 2>(), STAGE = NP * (KIMG + VIMG);
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
+    static_assert(RPP <= 64 && NPASS >= 1, "staging map");
+    constexpr int KS = DP / 16, DT = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    // workgroup -> (head, query block): consecutive workgroup ids go round-robin over the 8 XCDs, so give every XCD
+    // whole heads (their K / V then stay in that XCD's L2); causal: heaviest query blocks of a head first
+    int bh, qt;
+    {
+        const int L = blockIdx.x, nqt = prm.nqt;
+        if ((prm.BH & 7) == 0) {
+            const int x = L & 7, m = L >> 3;
+            bh = x + 8 * (m / nqt);
+            qt = m % nqt;
+        } else {
+            bh = L / nqt;
+            qt = L % nqt;
+        }
+        if (prm.causal) qt = nqt - 1 - qt;
+    }
+    const int b = bh / prm.H, hh = bh % prm.H;
+    const int D = prm.D, Nq = prm.Nq, Nk = prm.Nk;
+    const bool causal = prm.causal != 0;
+    const int i0 = qt * QT, qw0 = i0 + 32 * w, myq = qw0 + l31;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    Frag<NP> qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+
+    u32x4 rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
+    auto request = [&](int kt) {
+        kload.load(kt, rk);
+        vload.load(kt, rv);
+    };
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN, 1>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN, 2>(smem, stage * STAGE + NP * KIMG, srow + ps * RPP, scol, rv[ps]);
+        }
+    };
+    const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const float a = prm.a, c2 = 0.5f * prm.a * prm.a;
+
+    // f(a s) of one S^T tile (32 keys x 32 queries) -> the two B fragments (16 keys each) of the P^T operand
+    auto poly = [&](const f32x16& sc, int key0, auto masked_tag, Frag<NPP> (&pf)[2]) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float x;
+            if constexpr (P == 1) x = fmaf(sc[i], a, 1.0f);
+            else x = fmaf(sc[i], fmaf(sc[i], c2, a), 1.0f);
+            if constexpr (MASKED) {
+                const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const bool keep = key < Nk && (!causal || key <= myq);
+                x = keep ? x : 0.f;
+            }
+            pv[i] = x;
+            gsum[i & 3] += x;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 x0 = {pv[8 * s], pv[8 * s + 1], pv[8 * s + 2], pv[8 * s + 3]};
+            const f32x4 x1 = {pv[8 * s + 4], pv[8 * s + 5], pv[8 * s + 6], pv[8 * s + 7]};
+            if constexpr (NPP == 2) {
+                bf16x4 h0, l0, h1, l1;
+                split4(x0, h0, l0);
+                split4(x1, h1, l1);
+                pf[s].p[0] = cat4(h0, h1);
+                pf[s].p[1] = cat4(l0, l1);
+            } else {
+                pf[s].p[0] = cat4(to_bf16x4(x0), to_bf16x4(x1));
+            }
+        }
+    };
+
+    // One 64-key tile for this wave's 32 queries.  MASKED = the tile touches the causal diagonal or runs past N_k.
+    auto tile = [&](int kt, int stage, auto masked_tag) {
+        const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
+        f32x16 sc[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[jt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<NP> kf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) kf.p[p] = ld_row8<DP, 1>(smem, KI + p * KIMG, 32 * jt + l31, 2 * ks + h);
+                sc[jt] = mfma32_parts<NP, NP>(kf, qf[ks], sc[jt]);
+            }
+        }
+        Frag<NPP> pf[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            // V^T fragments of this key half are requested ahead of the polynomial so that they land behind it
+            Frag<NP> vf[2][DT];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) vf[s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32_parts<NP, NPP>(vf[s][dt], pf[jt][s], oacc[dt]);
+        }
+    };
+    // staging half of an iteration: tile kt+1 goes to the other stage (last read before the previous barrier), tile kt+2
+    // is requested
+    auto advance = [&](int kt) {
+        if (kt + 1 < nkt) {
+            commit((kt & 1) ^ 1);
+            if (kt + 2 < nkt) request(kt + 2);
+        }
+    };
+    // per wave: tiles [0, n_plain) lie wholly below the diagonal and inside N_k, [n_plain, n_act) need the masks,
+    // [n_act, nkt) lie wholly above the diagonal of this wave's queries (other waves of the workgroup still need them)
+    const int n_full = Nk / 64;
+    const int n_plain = causal ? min((qw0 + 1) / 64, n_full) : n_full;
+    const int n_act = causal ? min(nkt, (qw0 + 31) / 64 + 1) : nkt;
+
+    request(0);
+    commit(0);
+    if (nkt > 1) request(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt < n_plain; ++kt) {
+        advance(kt);
+        tile(kt, kt & 1, std::false_type{});
+        __syncthreads();
+    }
+    for (; kt < n_act; ++kt) {
+        advance(kt);
+        tile(kt, kt & 1, std::true_type{});
+        __syncthreads();
+    }
+    for (; kt < nkt; ++kt) {
+        advance(kt);
+        __syncthreads();
+    }
+
+    float gs = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+    gs += __shfl_xor(gs, 32, 64);
+    // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
+    const float gval = causal ? gs : gs - (float)Nk + prm.g0;
+    if (myq < Nq && prm.g && h == 0) prm.g[(int64_t)bh * Nq + myq] = gval;
+    const float ginv = 1.0f / gval;
+    // epilogue: 32 queries x 32 columns at a time through a wave-private 4 KiB area (the K / V stages are free after
+    // the loop's last barrier), written out as whole row segments
+    char* area = smem + w * 4096;
+    const bool out32 = prm.out_dtype == FASTMAX_F32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int ig = 0; ig < 4; ++ig) {
+            const f32x4 val = f32x4{oacc[dt][4 * ig], oacc[dt][4 * ig + 1], oacc[dt][4 * ig + 2], oacc[dt][4 * ig + 3]} * ginv;
+            if (out32) {
+                *reinterpret_cast<f32x4*>(area + l31 * 128 + ((((2 * ig + h) ^ l31) & 7) << 4)) = val;
+            } else {
+                char* dst = area + l31 * 64 + (((ig ^ l31) & 3) << 4) + (h << 3);
+                if (prm.out_dtype == FASTMAX_BF16) *reinterpret_cast<bf16x4*>(dst) = to_bf16x4(val);
+                else {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (_Float16)val[i];
+                    *reinterpret_cast<h4*>(dst) = o;
+                }
+            }
+        }
+        if (out32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = u * 64 + lane, rl = idx >> 3, cc = idx & 7;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(area + rl * 128 + (((cc ^ rl) & 7) << 4));
+                const int col = 32 * dt + 4 * cc;
+                if (qw0 + rl < Nq && col < D)
+                    __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(prm.o) + ((int64_t)bh * Nq + qw0 + rl) * D + col));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = u * 64 + lane, rl = idx >> 2, cc = idx & 3;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(area + rl * 64 + (((cc ^ rl) & 3) << 4));
+                const int col = 32 * dt + 8 * cc;
+                if (qw0 + rl < Nq && col < D)
+                    __builtin_nontemporal_store(val, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(prm.o) + ((int64_t)bh * Nq + qw0 + rl) * D + col));
+            }
+        }
+    }
+}
+
+template <int DP, int P, typename TIN, int NPP, int NW>
+static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP;
+    constexpr int stages = 2 * NP * (img_bytes<DP, 1>() + img_bytes<DP, 2>()), epi = NW * 4096;
+    constexpr int lds = stages > epi ? stages : epi;
+    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    prm.nqt = (prm.Nq + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL(kern, dim3(prm.nqt * prm.BH), dim3(64 * NW), lds, stream, prm);
+    return (int)hipGetLastError();
+}
+template <int DP, int P, typename TIN, int NPP>
+static int launch_quad32_n(const Quad32Params& prm, hipStream_t stream) {
+    static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_NW"); return e ? atoi(e) : 0; }();
+    const int nw = forced ? forced : 4;
+    return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4>(prm, stream);
+}
+template <int DP, int P, typename TIN>
+static int launch_quad32_t(const Quad32Params& prm, hipStream_t stream) {
+    if constexpr (InTraits<TIN>::NP == 1) {
+        if (prm.out_dtype != FASTMAX_F32) return launch_quad32_n<DP, P, TIN, 1>(prm, stream);
+    }
+    return launch_quad32_n<DP, P, TIN, 2>(prm, stream);
+}
+template <int P, typename TIN>
+static int launch_quad32_d(const Quad32Params& prm, hipStream_t stream) {
+    return prm.D <= 64 ? launch_quad32_t<64, P, TIN>(prm, stream) : launch_quad32_t<128, P, TIN>(prm, stream);
+}
+template <typename TIN>
+static int launch_quad32_p(const Quad32Params& prm, int p, hipStream_t stream) {
+    return p == 1 ? launch_quad32_d<1, TIN>(prm, stream) : launch_quad32_d<2, TIN>(prm, stream);
+}
+
+// worth it once a head has a few hundred queries; shorter problems stay on the 16-query-per-wave kernel
+bool quad32_supported(const fastmax_problem& p) {
+    static const int mode = [] { const char* e = getenv("FASTMAX_QUAD32"); return e ? atoi(e) : 1; }();
+    if (!mode) return false;
+    const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
+    return (p.D % epl) == 0 && p.D <= 128 && p.Nq >= 256 && (int64_t)p.B * p.H * ((p.Nq + 127) / 128) <= 0x7fffffff;
+}
+
+int launch_fwd_quad32(const FwdArgs& a) {
+    if (!quad32_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    Quad32Params prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, a.prob.H, a.prob.B * a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D,
+                     a.prob.causal, a.prob.out_dtype, 0, a.prob.a, a.prob.g0};
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return launch_quad32_p<float>(prm, a.prob.p, a.stream);
+        case FASTMAX_BF16: return launch_quad32_p<bf16_t>(prm, a.prob.p, a.stream);
+        case FASTMAX_F16: return launch_quad32_p<f16_t>(prm, a.prob.p, a.stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

@@ -14,6 +14,7 @@
 // are exact single parts.  Head sizes are padded to DP = 64 or 128 columns inside LDS only.
 #include "fastmax_mfma_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace fastmax {
@@ -34,7 +35,7 @@ struct QuadMfmaParams {
 template <int DP, typename TIN, int NPP> constexpr int quad_qg() { return 1; }
 
 // grid = (ceil(Nq/(64 QG)), B*H), block = 256, dynamic LDS = (QG + 2) * NP * 64*DP*2 bytes
-template <int DP, int P, typename TIN, int NPP>
+template <int DP, int P, typename TIN, int NPP, int PFD>
 __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int QG = quad_qg<DP, TIN, NPP>(), QT = 64 * QG;
@@ -78,14 +79,16 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
             }
         }
     }
-    u32x4 rk[NPASS], rv[NPASS];
+    // PFD key tiles are in flight in registers (K and V of tile kt + PFD are requested while tile kt is staged)
+    u32x4 rk[PFD][NPASS], rv[PFD][NPASS];
     const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
-    auto issue = [&](int kt) {
-        kload.load(kt, rk);
-        vload.load(kt, rv);
-    };
     const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
-    issue(0);
+#pragma unroll
+    for (int f = 0; f < PFD; ++f)
+        if (f < nkt) {
+            kload.load(f, rk[f]);
+            vload.load(f, rv[f]);
+        }
     __syncthreads();
     Frag<NP> qf[QG][KS];
     int qidx[QG];
@@ -176,17 +179,25 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
             }
         }
     };
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                                   // previous tile fully consumed
+    for (int kt0 = 0; kt0 < nkt; kt0 += PFD) {
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[ps]);
-            stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[ps]);
+        for (int f = 0; f < PFD; ++f) {
+            const int kt = kt0 + f;
+            if (kt >= nkt) break;
+            __syncthreads();                               // previous tile fully consumed
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                stage_piece<DP, TIN>(smem, KI, srow + ps * RPP, scol, rk[f][ps]);
+                stage_piece<DP, TIN>(smem, VI, srow + ps * RPP, scol, rv[f][ps]);
+            }
+            if (kt + PFD < nkt) {
+                kload.load(kt + PFD, rk[f]);
+                vload.load(kt + PFD, rv[f]);
+            }
+            __syncthreads();
+            if ((causal && (kt + 1) * 64 > i0) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
+            else tile(kt, std::false_type{});
         }
-        if (kt + 1 < nkt) issue(kt + 1);
-        __syncthreads();
-        if ((causal && (kt + 1) * 64 > i0) || (kt + 1) * 64 > Nk) tile(kt, std::true_type{});
-        else tile(kt, std::false_type{});
     }
     __syncthreads();                                       // K / V images free: they become the output staging area
 #pragma unroll
@@ -203,11 +214,11 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
     }
 }
 
-template <int DP, int P, typename TIN, int NPP>
-static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+template <int DP, int P, typename TIN, int NPP, int PFD>
+static int launch_quad_pf(const QuadMfmaParams& prm, int B, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP, QG = quad_qg<DP, TIN, NPP>();
     constexpr int lds = (QG + 2) * NP * 64 * DP * 2;
-    auto kern = fwd_quad_mfma_kernel<DP, P, TIN, NPP>;
+    auto kern = fwd_quad_mfma_kernel<DP, P, TIN, NPP, PFD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -217,6 +228,13 @@ static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
     dim3 grid((prm.Nq + 64 * QG - 1) / (64 * QG), B * prm.H), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, prm);
     return (int)hipGetLastError();
+}
+template <int DP, int P, typename TIN, int NPP>
+static int launch_quad_n(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+    static const int pfd = [] { const char* e = getenv("FASTMAX_QUAD_PFD"); return e ? atoi(e) : 1; }();
+    if (pfd == 2) return launch_quad_pf<DP, P, TIN, NPP, 2>(prm, B, stream);
+    if (pfd == 3) return launch_quad_pf<DP, P, TIN, NPP, 3>(prm, B, stream);
+    return launch_quad_pf<DP, P, TIN, NPP, 1>(prm, B, stream);
 }
 template <int DP, int P, typename TIN>
 static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {

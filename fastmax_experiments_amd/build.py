@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into fastmax_experiments_amd/libfastmax_hip.so."""
     if not force and not stale():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + SOURCES
+    extra = os.environ.get("FASTMAX_HIPCC_EXTRA", "").split()      # e.g. -DFASTMAX_QUAD32_ABLATION for tools/ablate builds
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -91,7 +91,7 @@ template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks
 }
 
 // 1-D grid of nqt * BH workgroups; block = 64 NW threads; dynamic LDS = max(2 stages of K,V images, NW * 4 KiB)
-template <int DP, int P, typename TIN, int NPP, int NW>
+template <int DP, int P, typename TIN, int NPP, int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) void fwd_quad32_kernel(Quad32Params prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int NT = 64 * NW, QT = 32 * NW;
@@ -188,47 +188,114 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     };
 
     // One 64-key tile for this wave's 32 queries.  MASKED = the tile touches the causal diagonal or runs past N_k.
+    // Software pipeline inside the wave (the two 32-key halves h0, h1 of the tile):
+    //     A: S(h0) = K(h0) Q^T            B: S(h1) = K(h1) Q^T  ||  P(h0) = f(S(h0)) on the vector ALU
+    //     C: O^T += V(h0)^T P(h0)^T  ||  P(h1) = f(S(h1))       D: O^T += V(h1)^T P(h1)^T
+    // B and C are issued as {1 MFMA, a few VALU} groups so the polynomial hides in the matrix pipe's shadow.
     auto tile = [&](int kt, int stage, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int QKM = KS * (NP == 2 ? 3 : 1);                   // MFMAs of one S chain
+        constexpr int PVM = 2 * DT * (1 + (NP == 2) + (NPP == 2));    // MFMAs of one key half of O^T += V^T P^T
+        constexpr int VPOLY = (P == 2 ? 16 : 8) + 8 + (NPP == 2 ? 40 : 8) + (MASKED ? 48 : 0);   // VALU of one poly()
         const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
         f32x16 sc[2];
+        if constexpr (ABL != 0) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[jt][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                Frag<NP> kf;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) kf.p[p] = ld_row8<DP, 1>(smem, KI + p * KIMG, 32 * jt + l31, 2 * ks + h);
-                sc[jt] = mfma32_parts<NP, NP>(kf, qf[ks], sc[jt]);
-            }
+            for (int i = 0; i < 16; ++i) { sc[0][i] = oacc[0][i]; sc[1][i] = oacc[DT - 1][i]; }
         }
-        Frag<NPP> pf[2][2];
+        Frag<NP> kf[2][KS];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            // V^T fragments of this key half are requested ahead of the polynomial so that they land behind it
-            Frag<NP> vf[2][DT];
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) kf[jt][ks].p[p] = ld_row8<DP, 1>(smem, KI + p * KIMG, 32 * jt + l31, 2 * ks + h);
+        Frag<NP> vf[2][2][DT];
+        if constexpr (ABL != 0) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = qf[dt].p[p];
+        }
+        auto vread = [&](int jt) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) vf[s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
+        };
+        auto qk = [&](int jt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[jt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sc[jt] = mfma32_parts<NP, NP>(kf[jt][ks], qf[ks], sc[jt]);
+        };
+        Frag<NPP> pf[2][2];
+        if constexpr (ABL != 0) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p = 0; p < NPP; ++p) pf[jt][s].p[p] = qf[s].p[0];
+        }
+        auto pv = [&](int jt) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32_parts<NP, NPP>(vf[s][dt], pf[jt][s], oacc[dt]);
+                for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32_parts<NP, NPP>(vf[jt][s][dt], pf[jt][s], oacc[dt]);
+        };
+        if constexpr (DP == 128) {
+            // A
+            qk(0);
+            vread(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // B
+            qk(1);
+            poly(sc[0], k0, masked_tag, pf[0]);
+#pragma unroll
+            for (int i = 0; i < QKM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (VPOLY + QKM - 1) / QKM, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // C
+            vread(1);
+            pv(0);
+            poly(sc[1], k0 + 32, masked_tag, pf[1]);
+#pragma unroll
+            for (int i = 0; i < PVM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, (VPOLY + PVM - 1) / PVM, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // D
+            pv(1);
+        } else {
+            // D <= 64 (measured): leaving the two S chains to the compiler and walling only the polynomial off, with the
+            // V^T fragments requested ahead of it, is 4 % faster than the grouped issue and needs no spill
+            if (!(ABL & 16)) { qk(0); qk(1); }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if (!(ABL & 8)) vread(jt);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 4)) poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 32)) pv(jt);
+            }
         }
     };
     // staging half of an iteration: tile kt+1 goes to the other stage (last read before the previous barrier), tile kt+2
     // is requested
     auto advance = [&](int kt) {
         if (kt + 1 < nkt) {
-            commit((kt & 1) ^ 1);
-            if (kt + 2 < nkt) request(kt + 2);
+            if (!(ABL & 1)) commit((kt & 1) ^ 1);
+            if (kt + 2 < nkt && !(ABL & 2)) request(kt + 2);
         }
     };
     // per wave: tiles [0, n_plain) lie wholly below the diagonal and inside N_k, [n_plain, n_act) need the masks,
@@ -308,12 +375,12 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     }
 }
 
-template <int DP, int P, typename TIN, int NPP, int NW>
+template <int DP, int P, typename TIN, int NPP, int NW, int ABL = 0>
 static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     constexpr int stages = 2 * NP * (img_bytes<DP, 1>() + img_bytes<DP, 2>()), epi = NW * 4096;
     constexpr int lds = stages > epi ? stages : epi;
-    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW>;
+    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -327,7 +394,26 @@ static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
 template <int DP, int P, typename TIN, int NPP>
 static int launch_quad32_n(const Quad32Params& prm, hipStream_t stream) {
     static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_NW"); return e ? atoi(e) : 0; }();
-    const int nw = forced ? forced : 4;
+    const int nw = forced ? forced : ((DP == 64 && InTraits<TIN>::NP == 1) ? 4 : 8);
+#ifdef FASTMAX_QUAD32_ABLATION
+    if constexpr (DP == 64 && P == 2 && InTraits<TIN>::NP == 1 && NPP == 1) {
+        static const int abl = [] { const char* e = getenv("FASTMAX_QUAD32_ABL"); return e ? atoi(e) : 0; }();
+        switch (abl) {
+            case 1: return launch_quad32_w<DP, P, TIN, NPP, 4, 1>(prm, stream);
+            case 3: return launch_quad32_w<DP, P, TIN, NPP, 4, 3>(prm, stream);
+            case 4: return launch_quad32_w<DP, P, TIN, NPP, 4, 4>(prm, stream);
+            case 8: return launch_quad32_w<DP, P, TIN, NPP, 4, 8>(prm, stream);
+            case 16: return launch_quad32_w<DP, P, TIN, NPP, 4, 16>(prm, stream);
+            case 24: return launch_quad32_w<DP, P, TIN, NPP, 4, 24>(prm, stream);
+            case 28: return launch_quad32_w<DP, P, TIN, NPP, 4, 28>(prm, stream);
+            case 31: return launch_quad32_w<DP, P, TIN, NPP, 4, 31>(prm, stream);
+            case 35: return launch_quad32_w<DP, P, TIN, NPP, 4, 35>(prm, stream);
+            case 60: return launch_quad32_w<DP, P, TIN, NPP, 4, 60>(prm, stream);
+            case 63: return launch_quad32_w<DP, P, TIN, NPP, 4, 63>(prm, stream);
+            default: break;
+        }
+    }
+#endif
     return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4>(prm, stream);
 }
 template <int DP, int P, typename TIN>

@@ -127,7 +127,8 @@ int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64
     // p=1 masked: linear-time scans (carried D x D state) unless the caller asks for the tile kernels
     const bool lin = prob->path != FASTMAX_PATH_QUADRATIC_MFMA && lin_bwd_supported(*prob) && prob->in_dtype == prob->out_dtype &&
                      !(reinterpret_cast<uintptr_t>(o) & 15);
-    return lin ? launch_bwd_lin(a) : launch_bwd_quad_mfma(a);
+    if (lin) return launch_bwd_lin(a);
+    return quad32_bwd_supported(*prob) ? launch_bwd_quad32(a) : launch_bwd_quad_mfma(a);
 }
 
 size_t fastmax_hip_normalize_workspace(int B, int H) { return sizeof(unsigned int) * (size_t)B * H; }

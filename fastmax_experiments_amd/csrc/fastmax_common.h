@@ -119,6 +119,9 @@ bool quad32_supported(const fastmax_problem& p);
 int launch_bwd_quadratic(const BwdArgs& a);
 int launch_bwd_quad_mfma(const BwdArgs& a);
 bool quad_mfma_bwd_supported(const fastmax_problem& p);
+int launch_bwd_quad32(const BwdArgs& a);
+int launch_bwd_quad32_main(const BwdArgs& a);
+bool quad32_bwd_supported(const fastmax_problem& p);
 int launch_bwd_lin(const BwdArgs& a);
 bool lin_bwd_supported(const fastmax_problem& p);
 size_t bwd_quadratic_workspace(const fastmax_problem& p);

@@ -22,12 +22,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     of one chunk column land on 16 distinct 16-byte slots
 //   2 (transposed reads, ds_read_b64_tr_b16): row stride 2 DP + 64 bytes -- the 4 consecutive rows x 64 bytes of a
 //     half-wave land on the four 64-byte quarters of the 256-byte bank row
-template <int DP, int SW = 0> constexpr int img_row_bytes() { return SW == 0 ? 2 * DP : (SW == 1 ? 2 * DP + 16 : 2 * DP + 64); }
+//   3: dense rows with an XOR key that serves BOTH kinds of read of 32-row fragments (an image that is read by rows for
+//     one product and transposed for another): key = (row bit 1, row bits 4:3) at 128-byte rows and
+//     (row bits 1:0, row bits 4:3) at 256-byte rows; costs one address register per (k-step, chunk block) variant
+template <int DP, int SW = 0> constexpr int img_row_bytes() { return (SW == 0 || SW == 3) ? 2 * DP : (SW == 1 ? 2 * DP + 16 : 2 * DP + 64); }
 template <int DP, int SW = 0> constexpr int img_bytes() { return 64 * img_row_bytes<DP, SW>(); }
 template <int DP, int SW = 0> __device__ __forceinline__ int img_off(int row, int chunk) {
     if constexpr (SW == 0) {
         if constexpr (DP == 64) return row * 128 + (((chunk ^ row) & 7) << 4);
         else return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+    } else if constexpr (SW == 3) {
+        if constexpr (DP == 64) return row * 128 + (((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 3) & 3))) & 7) << 4);
+        else return row * 256 + (((chunk ^ (((row & 3) << 2) | ((row >> 3) & 3))) & 15) << 4);
     } else {
         return row * img_row_bytes<DP, SW>() + (chunk << 4);
     }

@@ -1,0 +1,428 @@
+// fastmax backward (dQ, dK, dV; p = 1, 2; masked / unmasked) on 32x32x16 bf16 MFMA tiles (gfx950).
+//
+// Same dense gradients as fastmax_quad_mfma_bwd.hip (reference: attention_mechanisms/fastmax.py:383-691):
+//   s_ij = a q_i.k_j,  P = f(s),  w_i = 1/g_i,  c_i = G_i.o_i,  u_ij = G_i.v_j
+//   dS_ij = (u_ij - c_i) w_i f'(s_ij)        (only j <= i when causal)
+//   dQ_i = a sum_j dS_ij k_j ;  dK_j = a sum_i dS_ij q_i ;  dV_j = sum_i P_ij w_i G_i
+// in the structure of fastmax_quad32_mfma.hip: a wave owns 32 rows of the output (queries for dQ, keys for dK / dV),
+// its own operand rows sit in registers as B fragments (loaded once from global memory), the other side streams
+// through double-buffered LDS tiles with one barrier per tile, and the score-shaped tiles (S, U -> dS, P w) stay in
+// registers as the B operand of the second product.  An LDS tile that is read by rows for one product and
+// transposed for another (K for dQ; Q and G for dK / dV) uses the dual-use XOR image (img_off<DP, 3>).
+// Scores are recomputed in both kernels, so there are no atomics and the result is bitwise reproducible.
+#include "fastmax_mfma32_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace fastmax {
+
+struct Quad32BwdParams {
+    const void *q, *k, *v, *go;
+    const float *g, *c;             // g (B,H,Nq) from the forward, c_i = G_i.o_i (B,H,Nq) from bwd_prep
+    Strides3 qs, ks, vs, gos;
+    void *dq, *dk, *dv;
+    int H, BH, Nq, Nk, D, causal, grad_dtype, nblk;
+    float a;
+};
+
+// workgroup id -> (head, block): whole heads per XCD (see fastmax_quad32_mfma.hip)
+__device__ __forceinline__ void quad32_block(int L, int nblk, int BH, int& bh, int& blk) {
+    if ((BH & 7) == 0) {
+        const int x = L & 7, m = L >> 3;
+        bh = x + 8 * (m / nblk);
+        blk = m % nblk;
+    } else {
+        bh = L / nblk;
+        blk = L % nblk;
+    }
+}
+
+// f32x16 score-shaped tile -> two B fragments (16 k-rows each), NPP parts
+template <int NPP> __device__ __forceinline__ void pack_tile(const float (&x)[16], Frag<NPP> (&f)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 x0 = {x[8 * s], x[8 * s + 1], x[8 * s + 2], x[8 * s + 3]};
+        const f32x4 x1 = {x[8 * s + 4], x[8 * s + 5], x[8 * s + 6], x[8 * s + 7]};
+        if constexpr (NPP == 2) {
+            bf16x4 h0, l0, h1, l1;
+            split4(x0, h0, l0);
+            split4(x1, h1, l1);
+            f[s].p[0] = cat4(h0, h1);
+            f[s].p[1] = cat4(l0, l1);
+        } else {
+            f[s].p[0] = cat4(to_bf16x4(x0), to_bf16x4(x1));
+        }
+    }
+}
+
+// ---- dQ: one wave = 32 queries, NW waves per workgroup, loop over 64-key tiles ---------------------------------------------
+template <int DP, int P, typename TIN, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && (DP == 64 || InTraits<TIN>::NP == 1)) ? 2 : 1) void bwd32_dq_kernel(Quad32BwdParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
+    constexpr int NT = 64 * NW, QT = 32 * NW;
+    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG;          // K (dual use) then V (row reads)
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
+    static_assert(RPP <= 64 && NPASS >= 1, "staging map");
+    constexpr int KS = DP / 16, DT = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    int bh, qt;
+    quad32_block(blockIdx.x, prm.nblk, prm.BH, bh, qt);
+    const bool causal = prm.causal != 0;
+    if (causal) qt = prm.nblk - 1 - qt;                                   // heaviest query blocks first
+    const int b = bh / prm.H, hh = bh % prm.H;
+    const int D = prm.D, Nq = prm.Nq, Nk = prm.Nk;
+    const int i0 = qt * QT, qw0 = i0 + 32 * w, myq = qw0 + l31;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)hh * prm.gos.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    Frag<NP> qf[KS], gf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (P == 2) qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+        gf[ks] = load_q_frag<TIN>(gb, prm.gos.sn, myq, Nq, 16 * ks + 8 * h, D);
+    }
+    const int qc = myq < Nq ? myq : Nq - 1;
+    const float wi = 1.0f / prm.g[(int64_t)bh * Nq + qc];
+    const float ncw = -prm.c[(int64_t)bh * Nq + qc] * wi;                 // (u - c) w = u w + ncw
+    const float a = prm.a;
+
+    u32x4 rk[NPASS], rv[NPASS];
+    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
+    auto request = [&](int kt) {
+        kload.load(kt, rk);
+        vload.load(kt, rv);
+    };
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN, 3>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN, 3>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rv[ps]);
+        }
+    };
+    const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
+
+    f32x16 acc[DT];
+#pragma unroll
+    for (int mt = 0; mt < DT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    auto tile = [&](int kt, int stage, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int KI = stage * STAGE, VI = KI + NP * IMG, k0 = kt * 64;
+        Frag<NPP> df[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            f32x16 sc, u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; u[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<NP> kf, vf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    vf.p[p] = ld_row8<DP, 3>(smem, VI + p * IMG, 32 * jt + l31, 2 * ks + h);
+                    if constexpr (P == 2) kf.p[p] = ld_row8<DP, 3>(smem, KI + p * IMG, 32 * jt + l31, 2 * ks + h);
+                }
+                u = mfma32_parts<NP, NP>(vf, gf[ks], u);                       // u[j][i] = v_j . G_i
+                if constexpr (P == 2) sc = mfma32_parts<NP, NP>(kf, qf[ks], sc);   // s[j][i] = k_j . q_i
+            }
+            float ds[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = fmaf(u[i], wi, ncw);
+                if constexpr (P == 2) x *= fmaf(sc[i], a, 1.0f);
+                if constexpr (MASKED) {
+                    const int key = k0 + 32 * jt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const bool keep = key < Nk && (!causal || key <= myq);
+                    x = keep ? x : 0.f;
+                }
+                ds[i] = x;
+            }
+            pack_tile<NPP>(ds, df[jt]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    Frag<NP> ktf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8_32<DP, 3>(smem, KI + p * IMG, 32 * jt + 16 * s, 32 * mt, lane);
+                    acc[mt] = mfma32_parts<NP, NPP>(ktf, df[jt][s], acc[mt]);    // dQ^T[m][i] += K[j][m] dS[j][i]
+                }
+    };
+    auto advance = [&](int kt) {
+        if (kt + 1 < nkt) {
+            commit((kt & 1) ^ 1);
+            if (kt + 2 < nkt) request(kt + 2);
+        }
+    };
+    const int n_full = Nk / 64;
+    const int n_plain = causal ? min((qw0 + 1) / 64, n_full) : n_full;
+    const int n_act = causal ? min(nkt, (qw0 + 31) / 64 + 1) : nkt;
+
+    request(0);
+    commit(0);
+    if (nkt > 1) request(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt < n_plain; ++kt) {
+        advance(kt);
+        tile(kt, kt & 1, std::false_type{});
+        __syncthreads();
+    }
+    for (; kt < n_act; ++kt) {
+        advance(kt);
+        tile(kt, kt & 1, std::true_type{});
+        __syncthreads();
+    }
+    for (; kt < nkt; ++kt) {
+        advance(kt);
+        __syncthreads();
+    }
+    store_tile32_t<DT>(smem + w * 4096, acc, a, lane, prm.dq, prm.grad_dtype, (int64_t)bh * Nq, qw0, Nq, D);
+}
+
+// ---- dK, dV: one wave = 32 keys, NW waves per workgroup, loop over 64-query tiles -------------------------------------------
+// D <= 64 bf16 fits two waves per SIMD; the other variants hold 128..256 registers of fragments and accumulators per wave
+// and run one wave per SIMD with the accumulators in the AGPR half of the file
+template <int DP, int P, typename TIN, int NW>
+__global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW == 4) ? 2 : 1) void bwd32_dkv_kernel(Quad32BwdParams prm) {
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
+    constexpr int NT = 64 * NW, KT = 32 * NW;
+    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG + 512;      // Q, G (both dual use), w[64], -c w[64]
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
+    static_assert(RPP <= 64 && NPASS >= 1, "staging map");
+    constexpr int KS = DP / 16, DT = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    int bh, kb_;
+    quad32_block(blockIdx.x, prm.nblk, prm.BH, bh, kb_);                    // causal: low key blocks are the heavy ones, first
+    const bool causal = prm.causal != 0;
+    const int b = bh / prm.H, hh = bh % prm.H;
+    const int D = prm.D, Nq = prm.Nq, Nk = prm.Nk;
+    const int j0 = kb_ * KT, jw0 = j0 + 32 * w, myk = jw0 + l31;
+    const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
+    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
+    const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)hh * prm.gos.sh;
+    const int srow = tid / COLS, scol = tid % COLS;
+
+    Frag<NP> kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = load_q_frag<TIN>(kb, prm.ks.sn, myk, Nk, 16 * ks + 8 * h, D);
+        vf[ks] = load_q_frag<TIN>(vb, prm.vs.sn, myk, Nk, 16 * ks + 8 * h, D);
+    }
+    const float a = prm.a, c2 = 0.5f * prm.a * prm.a;
+
+    u32x4 rq[NPASS], rg[NPASS];
+    float rw = 0.f, rcw = 0.f;
+    const TileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, DP, srow, scol), gload(gb, prm.gos.sn, Nq, D, DP, srow, scol);
+    auto request = [&](int it) {
+        qload.load(it, rq);
+        gload.load(it, rg);
+        if (tid < 64) {
+            const int gi = it * 64 + tid, gc = gi < Nq ? gi : Nq - 1;
+            rw = 1.0f / prm.g[(int64_t)bh * Nq + gc];
+            rcw = -prm.c[(int64_t)bh * Nq + gc] * rw;
+        }
+    };
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            stage_piece<DP, TIN, 3>(smem, stage * STAGE, srow + ps * RPP, scol, rq[ps]);
+            stage_piece<DP, TIN, 3>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rg[ps]);
+        }
+        if (tid < 64) {
+            reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG)[tid] = rw;
+            reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG + 256)[tid] = rcw;
+        }
+    };
+    const int nqt = (Nq + 63) / 64;
+    const int it0 = causal ? min(j0 / 64, nqt) : 0;
+
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkacc[t][i] = 0.f; dvacc[t][i] = 0.f; }
+
+    auto tile = [&](int it, int stage, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int QI = stage * STAGE, GI = QI + NP * IMG, WS = GI + NP * IMG, CS = WS + 256;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x16 sc, u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; u[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<NP> qrf, grf;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    qrf.p[p] = ld_row8<DP, 3>(smem, QI + p * IMG, 32 * qs + l31, 2 * ks + h);
+                    grf.p[p] = ld_row8<DP, 3>(smem, GI + p * IMG, 32 * qs + l31, 2 * ks + h);
+                }
+                sc = mfma32_parts<NP, NP>(qrf, kf[ks], sc);                   // s[i][j]: rows = queries, col = key (lane)
+                u = mfma32_parts<NP, NP>(grf, vf[ks], u);                     // u[i][j] = G_i . v_j
+            }
+            Frag<NPP> pwf[2], dsf[2];
+            {
+                float pw[16], ds[16];
+#pragma unroll
+                for (int ig = 0; ig < 4; ++ig) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(smem + WS + (32 * qs + 8 * ig + 4 * h) * 4);
+                    const f32x4 cw4 = *reinterpret_cast<const f32x4*>(smem + CS + (32 * qs + 8 * ig + 4 * h) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * ig + e;
+                        float fv, fp;
+                        if constexpr (P == 1) { fv = fmaf(sc[i], a, 1.0f); fp = 1.0f; }
+                        else { fv = fmaf(sc[i], fmaf(sc[i], c2, a), 1.0f); fp = fmaf(sc[i], a, 1.0f); }
+                        float pwv = fv * w4[e];
+                        float dsv = fmaf(u[i], w4[e], cw4[e]) * fp;
+                        if constexpr (MASKED) {
+                            const int qi = it * 64 + 32 * qs + 8 * ig + 4 * h + e;
+                            const bool keep = qi < Nq && myk < Nk && (!causal || qi >= myk);
+                            pwv = keep ? pwv : 0.f;
+                            dsv = keep ? dsv : 0.f;
+                        }
+                        pw[i] = pwv;
+                        ds[i] = dsv;
+                    }
+                }
+                pack_tile<NPP>(pw, pwf);
+                pack_tile<NPP>(ds, dsf);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    Frag<NP> gtf, qtf;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        gtf.p[p] = ld_tr8_32<DP, 3>(smem, GI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
+                        qtf.p[p] = ld_tr8_32<DP, 3>(smem, QI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
+                    }
+                    dvacc[t] = mfma32_parts<NP, NPP>(gtf, pwf[s], dvacc[t]);        // dV^T[d][j] += G[i][d] P_ij w_i
+                    dkacc[t] = mfma32_parts<NP, NPP>(qtf, dsf[s], dkacc[t]);        // dK^T[m][j] += Q[i][m] dS_ij
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto advance = [&](int it) {
+        if (it + 1 < nqt) {
+            commit(((it - it0) & 1) ^ 1);
+            if (it + 2 < nqt) request(it + 2);
+        }
+    };
+    // per wave: query tiles [it0, it_a) lie wholly before this wave's keys (causal), [it_a, it_p) touch the diagonal,
+    // [it_p, n_fullq) are plain, the last one is partial when N_q % 64 != 0; a key block that runs past N_k masks all
+    const int n_fullq = Nq / 64;
+    int it_a = it0, it_p = it0;
+    if (causal) {
+        it_a = min(max(it0, jw0 / 64), nqt);
+        it_p = min(max(it_a, (jw0 + 31 + 63) / 64), nqt);
+    }
+    if (j0 + KT > Nk) it_p = nqt;
+    const int it_q = max(it_p, min(n_fullq, nqt));
+
+    if (it0 < nqt) {
+        request(it0);
+        commit(0);
+        if (it0 + 1 < nqt) request(it0 + 1);
+    }
+    __syncthreads();
+    int it = it0;
+    for (; it < it_a; ++it) {
+        advance(it);
+        __syncthreads();
+    }
+    for (; it < it_p; ++it) {
+        advance(it);
+        tile(it, (it - it0) & 1, std::true_type{});
+        __syncthreads();
+    }
+    for (; it < it_q; ++it) {
+        advance(it);
+        tile(it, (it - it0) & 1, std::false_type{});
+        __syncthreads();
+    }
+    for (; it < nqt; ++it) {
+        advance(it);
+        tile(it, (it - it0) & 1, std::true_type{});
+        __syncthreads();
+    }
+    store_tile32_t<DT>(smem + w * 4096, dkacc, a, lane, prm.dk, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
+    store_tile32_t<DT>(smem + w * 4096, dvacc, 1.0f, lane, prm.dv, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
+}
+
+template <int DP, int P, typename TIN, int NW>
+static int launch_bwd32_w(Quad32BwdParams prm, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP;
+    constexpr int st_q = 2 * 2 * NP * img_bytes<DP, 3>(), st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 512), epi = NW * 4096;
+    constexpr int lds_q = st_q > epi ? st_q : epi, lds_kv = st_kv > epi ? st_kv : epi;
+    auto kq = bwd32_dq_kernel<DP, P, TIN, NW>;
+    auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    prm.nblk = (prm.Nq + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL(kq, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_q, stream, prm);
+    prm.nblk = (prm.Nk + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL(kkv, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_kv, stream, prm);
+    return (int)hipGetLastError();
+}
+template <int DP, int P, typename TIN>
+static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
+    static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_BWD_NW"); return e ? atoi(e) : 0; }();
+    const int nw = forced ? forced : 4;
+    return nw == 8 ? launch_bwd32_w<DP, P, TIN, 8>(prm, stream) : launch_bwd32_w<DP, P, TIN, 4>(prm, stream);
+}
+template <int P, typename TIN>
+static int launch_bwd32_d(const Quad32BwdParams& prm, hipStream_t stream) {
+    return prm.D <= 64 ? launch_bwd32_n<64, P, TIN>(prm, stream) : launch_bwd32_n<128, P, TIN>(prm, stream);
+}
+template <typename TIN>
+static int launch_bwd32_p(const Quad32BwdParams& prm, int p, hipStream_t stream) {
+    return p == 1 ? launch_bwd32_d<1, TIN>(prm, stream) : launch_bwd32_d<2, TIN>(prm, stream);
+}
+
+bool quad32_bwd_supported(const fastmax_problem& p) {
+    static const int mode = [] { const char* e = getenv("FASTMAX_QUAD32_BWD"); return e ? atoi(e) : 1; }();
+    if (!mode) return false;
+    const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
+    return (p.D % epl) == 0 && p.D <= 128 && p.Nq >= 256 && p.Nk >= 256 && (int64_t)p.B * p.H * ((max(p.Nq, p.Nk) + 127) / 128) <= 0x7fffffff;
+}
+
+// c (B,H,Nq) = rowsum(G o) must already be in a.workspace (bwd_prep_kernel of fastmax_quad_mfma_bwd.hip)
+int launch_bwd_quad32_main(const BwdArgs& a) {
+    Quad32BwdParams prm{a.q, a.k, a.v, a.grad_o, a.g, reinterpret_cast<const float*>(a.workspace), a.qs, a.ks, a.vs, a.gos,
+                        a.dq, a.dk, a.dv, a.prob.H, a.prob.B * a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal,
+                        a.prob.in_dtype, 0, a.prob.a};
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return launch_bwd32_p<float>(prm, a.prob.p, a.stream);
+        case FASTMAX_BF16: return launch_bwd32_p<bf16_t>(prm, a.prob.p, a.stream);
+        case FASTMAX_F16: return launch_bwd32_p<f16_t>(prm, a.prob.p, a.stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

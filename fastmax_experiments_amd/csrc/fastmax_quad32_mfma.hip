@@ -12,14 +12,12 @@
 //   * f is two fused multiply-adds per element: 1 + s (a + s a^2/2)
 // 32x32x16 layouts (A: row = lane&31, k = 8(lane>>5)+j; B: col = lane&31, same k; C: col = lane&31,
 // row(i) = (i&3) + 8(i>>2) + 4(lane>>5)).
-#include "fastmax_mfma_common.h"
+#include "fastmax_mfma32_common.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace fastmax {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Quad32Params {
     const void *q, *k, *v;
@@ -29,60 +27,6 @@ struct Quad32Params {
     int H, BH, Nq, Nk, D, causal, out_dtype, nqt;
     float a, g0;
 };
-
-__device__ __forceinline__ f32x16 mfma32(const bf16x8 a, const bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-template <int NA, int NB>
-__device__ __forceinline__ f32x16 mfma32_parts(const Frag<NA>& a, const Frag<NB>& b, f32x16 c) {
-    c = mfma32(a.p[0], b.p[0], c);
-    if constexpr (NA == 2) c = mfma32(a.p[1], b.p[0], c);
-    if constexpr (NB == 2) c = mfma32(a.p[0], b.p[1], c);
-    return c;
-}
-
-// A operand of the 32x32x16 MFMA from a row-major image, transposed: lane (d = lane&31, h = lane>>5) receives
-// rows row0 + 4h + {0..3} and row0 + 8 + 4h + {0..3} of image column col0 + d  (= the key order of the accumulator
-// registers 8s..8s+7 of an S^T tile).
-template <int DP> __device__ __forceinline__ bf16x8 ld_tr8_32(const char* smem, int base, int row0, int col0, int lane) {
-    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-    const int ra = row0 + 4 * (g >> 1) + qq, rb = ra + 8;
-    const int col = col0 + 16 * (g & 1) + 4 * pp;
-    const int chunk = col >> 3, half = (col & 4) << 1;
-    union { bf16x8 v; s16x4 h[2]; } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP, 2>(ra, chunk) + half));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(smem + base + img_off<DP, 2>(rb, chunk) + half));
-    return u.v;
-}
-
-// 8 consecutive elements (columns col0..col0+7) of one query row -> B fragment part(s); zero outside the tensor
-template <typename TIN>
-__device__ __forceinline__ Frag<InTraits<TIN>::NP> load_q_frag(const TIN* base, int64_t sn, int row, int nrows, int col0, int D) {
-    constexpr int EPL = InTraits<TIN>::EPL, NP = InTraits<TIN>::NP;
-    Frag<NP> f;
-    if constexpr (NP == 1) {
-        f.p[0] = __builtin_bit_cast(bf16x8, load_piece<TIN>(base, sn, row, nrows, col0 / EPL, D));
-    } else {
-        float x[8];
-        if constexpr (EPL == 4) {
-            float lo4[4], hi4[4];
-            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4, D), lo4);
-            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4 + 1, D), hi4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { x[i] = lo4[i]; x[4 + i] = hi4[i]; }
-        } else {
-            piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 8, D), x);
-        }
-        bf16x4 h0, l0, h1, l1;
-        split4(f32x4{x[0], x[1], x[2], x[3]}, h0, l0);
-        split4(f32x4{x[4], x[5], x[6], x[7]}, h1, l1);
-        f.p[0] = cat4(h0, h1);
-        f.p[1] = cat4(l0, l1);
-    }
-    return f;
-}
 
 template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks() {
     // bf16 D<=64 with a 16-bit result needs ~166 registers: three 4-wave workgroups per CU; everything else two waves / SIMD
@@ -330,49 +274,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     const float gval = causal ? gs : gs - (float)Nk + prm.g0;
     if (myq < Nq && prm.g && h == 0) prm.g[(int64_t)bh * Nq + myq] = gval;
     const float ginv = 1.0f / gval;
-    // epilogue: 32 queries x 32 columns at a time through a wave-private 4 KiB area (the K / V stages are free after
-    // the loop's last barrier), written out as whole row segments
-    char* area = smem + w * 4096;
-    const bool out32 = prm.out_dtype == FASTMAX_F32;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int ig = 0; ig < 4; ++ig) {
-            const f32x4 val = f32x4{oacc[dt][4 * ig], oacc[dt][4 * ig + 1], oacc[dt][4 * ig + 2], oacc[dt][4 * ig + 3]} * ginv;
-            if (out32) {
-                *reinterpret_cast<f32x4*>(area + l31 * 128 + ((((2 * ig + h) ^ l31) & 7) << 4)) = val;
-            } else {
-                char* dst = area + l31 * 64 + (((ig ^ l31) & 3) << 4) + (h << 3);
-                if (prm.out_dtype == FASTMAX_BF16) *reinterpret_cast<bf16x4*>(dst) = to_bf16x4(val);
-                else {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    h4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (_Float16)val[i];
-                    *reinterpret_cast<h4*>(dst) = o;
-                }
-            }
-        }
-        if (out32) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = u * 64 + lane, rl = idx >> 3, cc = idx & 7;
-                const f32x4 val = *reinterpret_cast<const f32x4*>(area + rl * 128 + (((cc ^ rl) & 7) << 4));
-                const int col = 32 * dt + 4 * cc;
-                if (qw0 + rl < Nq && col < D)
-                    __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(prm.o) + ((int64_t)bh * Nq + qw0 + rl) * D + col));
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = u * 64 + lane, rl = idx >> 2, cc = idx & 3;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(area + rl * 64 + (((cc ^ rl) & 3) << 4));
-                const int col = 32 * dt + 8 * cc;
-                if (qw0 + rl < Nq && col < D)
-                    __builtin_nontemporal_store(val, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(prm.o) + ((int64_t)bh * Nq + qw0 + rl) * D + col));
-            }
-        }
-    }
+    store_tile32_t<DT>(smem + w * 4096, oacc, ginv, lane, prm.o, prm.out_dtype, (int64_t)bh * Nq, qw0, Nq, D);
 }
 
 template <int DP, int P, typename TIN, int NPP, int NW, int ABL = 0>

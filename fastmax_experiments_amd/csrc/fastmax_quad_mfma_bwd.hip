@@ -351,6 +351,24 @@ bool quad_mfma_bwd_supported(const fastmax_problem& p) {
     return (p.D % epl) == 0 && p.D <= 128;
 }
 
+// 32x32-tile kernels (fastmax_quad32_bwd.hip) behind the same prep launch
+int launch_bwd_quad32(const BwdArgs& a) {
+    if (!quad32_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;
+    QuadBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
+                      reinterpret_cast<float*>(a.workspace), a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal,
+                      a.prob.in_dtype, a.prob.out_dtype, a.prob.a};
+    const dim3 grid((prm.Nq + 3) / 4, a.prob.B * a.prob.H);
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: hipLaunchKernelGGL((bwd_prep_kernel<float>), grid, dim3(256), 0, a.stream, prm); break;
+        case FASTMAX_BF16: hipLaunchKernelGGL((bwd_prep_kernel<bf16_t>), grid, dim3(256), 0, a.stream, prm); break;
+        case FASTMAX_F16: hipLaunchKernelGGL((bwd_prep_kernel<f16_t>), grid, dim3(256), 0, a.stream, prm); break;
+        default: return FASTMAX_E_BAD_DTYPE;
+    }
+    const int e = (int)hipGetLastError();
+    return e ? e : launch_bwd_quad32_main(a);
+}
+
 int launch_bwd_quad_mfma(const BwdArgs& a) {
     if (!quad_mfma_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
     if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;

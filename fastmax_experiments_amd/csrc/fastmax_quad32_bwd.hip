@@ -393,7 +393,7 @@ static int launch_bwd32_w(Quad32BwdParams prm, hipStream_t stream) {
 template <int DP, int P, typename TIN>
 static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
     static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_BWD_NW"); return e ? atoi(e) : 0; }();
-    const int nw = forced ? forced : 4;
+    const int nw = forced ? forced : ((DP == 64 && InTraits<TIN>::NP == 2) ? 8 : 4);
     return nw == 8 ? launch_bwd32_w<DP, P, TIN, 8>(prm, stream) : launch_bwd32_w<DP, P, TIN, 4>(prm, stream);
 }
 template <int P, typename TIN>

@@ -43,6 +43,62 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(QuadBwdParams prm) {
     if (lane == 0) prm.c[(int64_t)bh * prm.Nq + i] = s;
 }
 
+// Vectorised c_i = G_i . o_i for head sizes with a power-of-two number of 16-byte pieces per row: LPR lanes per row,
+// 256 / LPR rows per block, 16-byte loads of G and o.  grid = (ceil(Nq / (256/LPR)), B*H)
+template <typename TIN, int LPR>
+__global__ __launch_bounds__(256) void bwd_prep_vec_kernel(QuadBwdParams prm) {
+    constexpr int EPL = InTraits<TIN>::EPL, RPB = 256 / LPR;
+    const int tid = threadIdx.x, sub = tid % LPR;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int i = blockIdx.x * RPB + tid / LPR;
+    const bool live = i < prm.Nq;
+    const int ic = live ? i : prm.Nq - 1;
+    const TIN* grow = row_ptr<TIN>(prm.go, prm.gos.sb, prm.gos.sh, prm.gos.sn, b, h, ic);
+    float x[EPL], y[EPL];
+    piece_to_float<TIN>(*reinterpret_cast<const u32x4*>(grow + sub * EPL), x);
+    const int64_t ob = ((int64_t)bh * prm.Nq + ic) * prm.D + sub * EPL;
+    if (prm.o_dtype == FASTMAX_F32) {
+#pragma unroll
+        for (int e4 = 0; e4 < EPL / 4; ++e4) {
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(prm.o) + ob + 4 * e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * e4 + e] = o4[e];
+        }
+    } else {      // 16-bit o has the input dtype (masked outputs; fastmax.py:100-106)
+        if constexpr (sizeof(TIN) == 2) piece_to_float<TIN>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const TIN*>(prm.o) + ob), y);
+        else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) y[e] = load_elem(prm.o, prm.o_dtype, ob + e);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s = fmaf(x[e], y[e], s);
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (live && sub == 0) prm.c[(int64_t)bh * prm.Nq + i] = s;
+}
+
+template <typename TIN>
+static void launch_prep(const QuadBwdParams& prm, int BH, hipStream_t stream) {
+    constexpr int EPL = InTraits<TIN>::EPL;
+    const int lpr = prm.D / EPL;
+    const bool vec = prm.D % EPL == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32) && (prm.gos.sn % EPL) == 0 &&
+                     (prm.gos.sh % EPL) == 0 && (prm.gos.sb % EPL) == 0 && !(reinterpret_cast<uintptr_t>(prm.go) & 15) &&
+                     !(reinterpret_cast<uintptr_t>(prm.o) & 15) && (sizeof(TIN) == 2 || prm.o_dtype == FASTMAX_F32);
+    if (!vec) {
+        hipLaunchKernelGGL((bwd_prep_kernel<TIN>), dim3((prm.Nq + 3) / 4, BH), dim3(256), 0, stream, prm);
+        return;
+    }
+    const dim3 grid((prm.Nq + 256 / lpr - 1) / (256 / lpr), BH);
+    switch (lpr) {
+        case 4: hipLaunchKernelGGL((bwd_prep_vec_kernel<TIN, 4>), grid, dim3(256), 0, stream, prm); break;
+        case 8: hipLaunchKernelGGL((bwd_prep_vec_kernel<TIN, 8>), grid, dim3(256), 0, stream, prm); break;
+        case 16: hipLaunchKernelGGL((bwd_prep_vec_kernel<TIN, 16>), grid, dim3(256), 0, stream, prm); break;
+        default: hipLaunchKernelGGL((bwd_prep_vec_kernel<TIN, 32>), grid, dim3(256), 0, stream, prm); break;
+    }
+}
+
 // ---- dQ: grid = (ceil(Nq/64), B*H), block = 256, LDS = 4*NP*IMG ------------------------------------
 template <int DP, int P, typename TIN>
 __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
@@ -332,7 +388,7 @@ static int launch_bwd_t(const QuadBwdParams& prm, int B, hipStream_t stream) {
         attr_set = true;
     }
     const int BH = B * prm.H;
-    hipLaunchKernelGGL((bwd_prep_kernel<TIN>), dim3((prm.Nq + 3) / 4, BH), dim3(256), 0, stream, prm);
+    launch_prep<TIN>(prm, BH, stream);
     hipLaunchKernelGGL(kq, dim3((prm.Nq + 63) / 64, BH), dim3(256), lds_q, stream, prm);
     hipLaunchKernelGGL(kkv, dim3((prm.Nk + 63) / 64, BH), dim3(256), lds_kv, stream, prm);
     return (int)hipGetLastError();
@@ -358,11 +414,10 @@ int launch_bwd_quad32(const BwdArgs& a) {
     QuadBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                       reinterpret_cast<float*>(a.workspace), a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal,
                       a.prob.in_dtype, a.prob.out_dtype, a.prob.a};
-    const dim3 grid((prm.Nq + 3) / 4, a.prob.B * a.prob.H);
     switch (a.prob.in_dtype) {
-        case FASTMAX_F32: hipLaunchKernelGGL((bwd_prep_kernel<float>), grid, dim3(256), 0, a.stream, prm); break;
-        case FASTMAX_BF16: hipLaunchKernelGGL((bwd_prep_kernel<bf16_t>), grid, dim3(256), 0, a.stream, prm); break;
-        case FASTMAX_F16: hipLaunchKernelGGL((bwd_prep_kernel<f16_t>), grid, dim3(256), 0, a.stream, prm); break;
+        case FASTMAX_F32: launch_prep<float>(prm, a.prob.B * a.prob.H, a.stream); break;
+        case FASTMAX_BF16: launch_prep<bf16_t>(prm, a.prob.B * a.prob.H, a.stream); break;
+        case FASTMAX_F16: launch_prep<f16_t>(prm, a.prob.B * a.prob.H, a.stream); break;
         default: return FASTMAX_E_BAD_DTYPE;
     }
     const int e = (int)hipGetLastError();

@@ -470,3 +470,69 @@ def test_randomised_shapes_against_oracle():
         e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
         for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
             assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, tag + (n,)
+
+
+# ---- 32x32x16-tile kernels (N >= 256): forward, dQ, dK/dV against the C oracle --------------------------------------
+Q32_CASES = [
+    # (B, H, Nq, Nk, D), p, mask
+    ((1, 8, 256, 256, 64), 2, True), ((2, 3, 300, 300, 64), 2, True), ((1, 2, 333, 333, 128), 2, True),
+    ((1, 5, 520, 520, 32), 1, True), ((1, 2, 384, 384, 80), 2, True), ((1, 16, 640, 640, 64), 2, False),
+    ((1, 2, 257, 400, 64), 2, False), ((1, 3, 500, 290, 128), 1, False), ((1, 2, 1100, 1100, 64), 2, True),
+]
+
+
+@pytest.mark.parametrize("dt,tf,tb", [(torch.float32, TOL_FWD, TOL_BWD), (torch.bfloat16, 8e-3, 2.5e-2), (torch.float16, 2e-3, 5e-3)])
+@pytest.mark.parametrize("shape,p,mask", Q32_CASES)
+def test_wide_tile_kernels_forward_backward(shape, p, mask, dt, tf, tb):
+    """quadratic family forced, sizes that route to fastmax_quad32_mfma.hip / fastmax_quad32_bwd.hip: ragged lengths,
+    padded head sizes, head counts that are / are not a multiple of the 8 XCDs, N_q != N_k (unmasked)"""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import c_oracle
+    B, H, Nq, Nk, D = shape
+    g = torch.Generator().manual_seed(Nq + Nk + D + p)
+    q, go = (torch.randn(B, H, Nq, D, generator=g).to(dt) for _ in range(2))
+    k, v = (torch.randn(B, H, Nk, D, generator=g).to(dt) for _ in range(2))
+    _force("quadratic_mfma")
+    qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o = fastmax(qq, kk, vv, mask=mask, p=p)
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=mask, p=p)
+    assert rel_err(o.detach().float().cpu().numpy(), ro) < (tf if o.dtype == dt else max(tf, TOL_FWD))
+    o.backward(go.cuda().to(o.dtype))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
+    for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+        assert t.grad.dtype == dt
+        assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, n
+
+
+def test_narrow_tile_kernels_still_serve_long_sequences():
+    """FASTMAX_QUAD32=0 / FASTMAX_QUAD32_BWD=0 (read once per process) keep the 16-row-tile kernels on every size:
+    run them at N >= 256 in a child process against the C oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import rel_err
+from attention_mechanisms.fastmax import fastmax
+from fastmax_experiments_amd import _lib, ops
+from oracle import c_oracle
+ops.set_forced_path(_lib.PATH_QUADRATIC_MFMA)
+for (B, H, N, D, p, mask, dt, tf, tb) in [(1, 3, 300, 64, 2, True, torch.float32, 2e-4, 1e-3), (1, 2, 520, 128, 2, True, torch.bfloat16, 8e-3, 2.5e-2),
+                                          (1, 8, 384, 32, 1, False, torch.float16, 2e-3, 5e-3)]:
+    g = torch.Generator().manual_seed(N)
+    q, k, v, go = (torch.randn(B, H, N, D, generator=g).to(dt) for _ in range(4))
+    qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o = fastmax(qq, kk, vv, mask=mask, p=p)
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=mask, p=p)
+    assert rel_err(o.detach().float().cpu().numpy(), ro) < max(tf, 2e-4), (N, "fwd")
+    o.backward(go.cuda().to(o.dtype))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
+    for t, rr in zip((qq, kk, vv), e):
+        assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, (N, "bwd")
+print("narrow ok")
+''' % (root, root)
+    env = dict(os.environ, FASTMAX_QUAD32="0", FASTMAX_QUAD32_BWD="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "narrow ok" in r.stdout, r.stdout + r.stderr

@@ -13,13 +13,15 @@ F32, BF16, F16 = 0, 1, 2
 PATH_AUTO, PATH_QUADRATIC, PATH_RECURRENT, PATH_MFMA, PATH_QUADRATIC_MFMA = 0, 1, 2, 3, 4
 PATH_NAMES = {PATH_AUTO: "auto", PATH_QUADRATIC: "quadratic", PATH_RECURRENT: "recurrent", PATH_MFMA: "mfma", PATH_QUADRATIC_MFMA: "quadratic_mfma"}
 E_BAD_P = -1
+E_BAD_SHAPE = -2
 
 # every symbol include/fastmax_hip.h declares
 SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_backward_workspace",
            "fastmax_hip_backward", "fastmax_hip_normalize_workspace", "fastmax_hip_normalize",
            "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string",
            "fastmax_hip_decode_state_bytes", "fastmax_hip_p1_prefill_state", "fastmax_hip_p1_decode_step",
-           "fastmax_hip_normalize_stats", "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
+           "fastmax_hip_normalize_stats", "fastmax_hip_normalize_cast", "fastmax_hip_normalize_backward_workspace",
+           "fastmax_hip_normalize_backward", "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
 
 
 class Problem(ctypes.Structure):
@@ -60,6 +62,12 @@ def lib():
     L.fastmax_hip_normalize.restype = ci
     L.fastmax_hip_normalize_stats.argtypes = [vp, i64p, ci, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize_stats.restype = ci
+    L.fastmax_hip_normalize_cast.argtypes = [vp, i64p, ci, vp, fp, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_cast.restype = ci
+    L.fastmax_hip_normalize_backward_workspace.argtypes = [ci, ci, ci]
+    L.fastmax_hip_normalize_backward_workspace.restype = sz
+    L.fastmax_hip_normalize_backward.argtypes = [vp, i64p, ci, vp, fp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_backward.restype = ci
     L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp, sz, vp]
     L.fastmax_hip_linearmax_forward.restype = ci
     i64 = ctypes.c_int64

@@ -14,17 +14,29 @@ from .fastmax import _KERNEL_DTYPES, fastattention_einops
 
 
 class _NormalizeQK(torch.autograd.Function):
-    """y = (x - mean_D x) / max_n ||x_n - mean_D x_n||   (fastmax_hack.py:38-43), float32 out."""
+    """y = (x - mean_D x) / max_n ||x_n - mean_D x_n||   (fastmax_hack.py:38-43), in x's dtype; forward and backward
+    in libfastmax_hip.so (fastmax_normalize.hip).  Head sizes that are not a whole number of 16-byte pieces take the
+    float32 kernel and the tensor-op backward below."""
 
     @staticmethod
     def forward(ctx, x):
+        r = ops.normalize_cast(x)
+        if r is not None:
+            y, inv = r
+            ctx.save_for_backward(x, inv)
+            ctx.fused = True
+            return y
         y, inv = ops.normalize(x)
         ctx.save_for_backward(y, inv)
         ctx.in_dtype = x.dtype
-        return y
+        ctx.fused = False
+        return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.fused:
+            x, inv = ctx.saved_tensors
+            return ops.normalize_backward(x, gy, inv)
         y, inv = ctx.saved_tensors                     # y = xc / M, inv = 1 / M
         gy = gy.float()
         gxc = gy * inv[..., None, None]
@@ -52,7 +64,7 @@ def fastmax_hack(q, k, v, p=1, mask=True):
     # training (or shapes the fused kernel does not cover): prologue and attention as separate autograd nodes,
     # both in libfastmax_hip.so; 16-bit inputs keep their dtype between the two, like the reference
     vd = ops._prep(v.to(kdt), dev)
-    qn, kn = _NormalizeQK.apply(qd).to(kdt), _NormalizeQK.apply(kd).to(kdt)
+    qn, kn = _NormalizeQK.apply(qd), _NormalizeQK.apply(kd)
     if not mask:
         # fastmax_hack.py:6-33: first order whatever p is; constant term N_k; result float32 for
         # low-precision inputs (float32 ones at line 21), float64 stays float64

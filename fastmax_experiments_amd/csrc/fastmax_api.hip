@@ -151,6 +151,31 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
                                   reinterpret_cast<hipStream_t>(stream));
 }
 
+int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm, int B, int H,
+                               int N, int D, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !x_strides || !y || !inv_norm) return FASTMAX_E_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
+    const int es = dtype == FASTMAX_F32 ? 4 : 2;
+    if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
+    if ((D * es) % 16 != 0 || D * es > 512) return FASTMAX_E_BAD_SHAPE;
+    int rc = launch_normalize_stats(x, st(x_strides), dtype, inv_norm, B, H, N, D, workspace, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    return launch_normalize_cast(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t fastmax_hip_normalize_backward_workspace(int B, int H, int N) { return normalize_backward_workspace(B, H, N); }
+
+int fastmax_hip_normalize_backward(const void* x, const int64_t* x_strides, int dtype, const void* grad_y, const float* inv_norm,
+                                   void* grad_x, int B, int H, int N, int D, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (!x || !x_strides || !grad_y || !inv_norm || !grad_x) return FASTMAX_E_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < normalize_backward_workspace(B, H, N)) return FASTMAX_E_WORKSPACE;
+    return launch_normalize_backward(x, st(x_strides), dtype, grad_y, inv_norm, grad_x, B, H, N, D, workspace,
+                                     reinterpret_cast<hipStream_t>(stream));
+}
+
 int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                   const int64_t* k_strides, const void* v, const int64_t* v_strides,
                                   const float* q_inv_norm, const float* k_inv_norm, void* o, float* g, void* workspace,

@@ -1,0 +1,243 @@
+// linearmax prologue for the training route (reference: attention_mechanisms/fastmax_hack.py:38-43, fastmax.py:326-334):
+//     y = (x - mean_D x) / M,   M = max_n || x_n - mean_D x_n ||      per (b,h)
+// written in the INPUT dtype (the reference keeps 16-bit tensors 16-bit between the prologue and the attention), and its
+// backward (the reference gets it from autograd over the same ops):
+//     gxc = gy / M;   dL/dM = -sum_{n,d}(gy y) / M;   gxc[n*] += dL/dM y[n*]  (n* = first argmax_n of the row norm);
+//     gx = gxc - mean_D gxc
+// Rows are spread over LPR lanes with 16-byte loads (scalar loads for unaligned views).  The backward is two launches:
+// per-block partials (sum gy.xc, best (norm^2, n)) then the row pass; partials are combined in a fixed order, so the
+// result is bitwise reproducible.
+#include "fastmax_common.h"
+
+namespace fastmax {
+
+typedef unsigned int nu32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct RowPiece {
+    static constexpr int EPL = 16 / sizeof(T);
+    float v[EPL];
+};
+
+// elements [sub*EPL, sub*EPL + EPL) of a row as floats (zero past D)
+template <typename T>
+__device__ __forceinline__ void load_row_piece(const T* row, int sub, int D, int vec, float (&v)[16 / sizeof(T)]) {
+    constexpr int EPL = 16 / sizeof(T);
+    if (vec) {
+        nu32x4 raw = {0, 0, 0, 0};
+        if (sub * EPL < D) raw = *reinterpret_cast<const nu32x4*>(row + sub * EPL);
+        const T* pv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = to_float(pv[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = (sub * EPL + e) < D ? to_float(row[sub * EPL + e]) : 0.f;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_row_piece(T* row, int sub, int D, int vec, const float (&v)[16 / sizeof(T)]) {
+    constexpr int EPL = 16 / sizeof(T);
+    if (vec) {
+        if (sub * EPL < D) {
+            nu32x4 raw;
+            T* pv = reinterpret_cast<T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) pv[e] = from_float<T>(v[e]);
+            *reinterpret_cast<nu32x4*>(row + sub * EPL) = raw;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (sub * EPL + e < D) row[sub * EPL + e] = from_float<T>(v[e]);
+    }
+}
+template <int LPR> __device__ __forceinline__ float group_sum(float s) {
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// ---- forward: y (dtype T, contiguous) = (x - mean) * inv[bh];  grid = (ceil(N / (256/LPR) / RPT), B*H) -----------------
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void normalize_cast_kernel(const void* x, Strides3 xs, int H, int N, int D, const float* inv_norm,
+                                                             T* y, int vec) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+    const int tid = threadIdx.x, sub = tid % LPR, rgrp = tid / LPR;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
+        float v[EPL];
+        load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += v[e];
+        const float mean = group_sum<LPR>(s) * invD;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mean) * inv;
+        store_row_piece<T>(y + ((int64_t)bh * N + n) * D, sub, D, vec, v);
+    }
+}
+
+// ---- backward, pass 1: per block  sum_n gy_n . xc_n  and the best (||xc_n||^2, first n) ------------------------------------
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void normalize_bwd_reduce_kernel(const void* x, Strides3 xs, const T* gy, int H, int N, int D,
+                                                                   float* part_dot, unsigned long long* part_best, int vec) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+    __shared__ float sdot[4];
+    __shared__ unsigned long long sbest[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid % LPR, rgrp = tid / LPR;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const float invD = 1.0f / (float)D;
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    float dot = 0.f;
+    unsigned long long best = 0ull;
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
+        float v[EPL], gv[EPL];
+        load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += v[e];
+        const float mean = group_sum<LPR>(s) * invD;
+        float nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float c = (sub * EPL + e) < D ? v[e] - mean : 0.f;
+            nn = fmaf(c, c, nn);
+            dot = fmaf(gv[e], c, dot);
+        }
+        nn = group_sum<LPR>(nn);
+        // squared norms are >= 0: their bit patterns order like unsigned integers; ties -> the smallest n (torch.argmax)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(nn) << 32) | (unsigned long long)(0xffffffffu - (unsigned)n);
+        best = key > best ? key : best;
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) { sdot[wave] = dot; sbest[wave] = best; }
+    __syncthreads();
+    if (tid == 0) {
+        const int idx = bh * gridDim.x + blockIdx.x;
+        part_dot[idx] = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
+        unsigned long long m = sbest[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = sbest[i] > m ? sbest[i] : m;
+        part_best[idx] = m;
+    }
+}
+
+// ---- backward, pass 2: the row pass ---------------------------------------------------------------------------------------
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void normalize_bwd_apply_kernel(const void* x, Strides3 xs, const T* gy, const float* inv_norm,
+                                                                  const float* part_dot, const unsigned long long* part_best,
+                                                                  int H, int N, int D, T* gx, int vec) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+    const int tid = threadIdx.x, sub = tid % LPR, rgrp = tid / LPR;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    float S = 0.f;
+    unsigned long long best = 0ull;
+    for (int i = 0; i < (int)gridDim.x; ++i) {                     // fixed order: reproducible
+        S += part_dot[bh * gridDim.x + i];
+        const unsigned long long o = part_best[bh * gridDim.x + i];
+        best = o > best ? o : best;
+    }
+    const int nstar = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+    const float dLdM = -(S * inv) * inv;                           // -sum(gy y) / M,  y = xc / M
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
+        float gv[EPL];
+        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] *= inv;
+        if (n == nstar) {                                          // uniform per row group
+            float v[EPL];
+            load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s += v[e];
+            const float mean = group_sum<LPR>(s) * invD;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (sub * EPL + e < D) gv[e] = fmaf(dLdM, (v[e] - mean) * inv, gv[e]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += gv[e];
+        const float gm = group_sum<LPR>(s) * invD;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] -= gm;
+        store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+    }
+}
+
+static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
+    const int epl = (int)(16 / es);
+    return (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((xs.sb * es) % 16 == 0) && ((xs.sh * es) % 16 == 0) &&
+           ((xs.sn * es) % 16 == 0) && (D % epl == 0);
+}
+#define NRM_LPR_SWITCH(need, CALL)      \
+    if ((need) <= 4) { CALL(4); }       \
+    else if ((need) <= 8) { CALL(8); }  \
+    else if ((need) <= 16) { CALL(16); } \
+    else { CALL(32); }
+
+template <typename T>
+static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream) {
+    const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
+    if (need > 32 || D % epl != 0 || (reinterpret_cast<uintptr_t>(y) & 15)) return FASTMAX_E_BAD_SHAPE;
+    const int vec = nrm_vec_ok(x, xs, sizeof(T), D);
+    const dim3 grid((N + 255) / 256, B * H), block(256);
+#define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec)
+    NRM_LPR_SWITCH(need, CALL)
+#undef CALL
+    return (int)hipGetLastError();
+}
+int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const float* inv_norm, int B, int H, int N, int D,
+                          hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: return normalize_cast_t<float>(x, xs, y, inv_norm, B, H, N, D, stream);
+        case FASTMAX_BF16: return normalize_cast_t<bf16_t>(x, xs, y, inv_norm, B, H, N, D, stream);
+        case FASTMAX_F16: return normalize_cast_t<f16_t>(x, xs, y, inv_norm, B, H, N, D, stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+size_t normalize_backward_workspace(int B, int H, int N) {
+    return (size_t)B * H * ((N + 255) / 256) * (sizeof(float) + sizeof(unsigned long long)) + 16;
+}
+
+template <typename T>
+static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const float* inv_norm, void* gx, int B, int H, int N, int D,
+                           void* ws, hipStream_t stream) {
+    const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
+    if (need > 32 || D % epl != 0 || ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15)) return FASTMAX_E_BAD_SHAPE;
+    const int vec = nrm_vec_ok(x, xs, sizeof(T), D);
+    const int nblk = (N + 255) / 256;
+    // 8-byte records first (alignment), then the floats
+    unsigned long long* part_best = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);
+    float* part_dot = reinterpret_cast<float*>(part_best + (size_t)B * H * nblk);
+    const dim3 grid(nblk, B * H), block(256);
+#define CALL(L)                                                                                                                   \
+    hipLaunchKernelGGL((normalize_bwd_reduce_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), H, N, D,  \
+                       part_dot, part_best, vec);                                                                                 \
+    hipLaunchKernelGGL((normalize_bwd_apply_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), inv_norm,  \
+                       part_dot, part_best, H, N, D, reinterpret_cast<T*>(gx), vec)
+    NRM_LPR_SWITCH(need, CALL)
+#undef CALL
+    return (int)hipGetLastError();
+}
+int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void* gy, const float* inv_norm, void* gx, int B, int H,
+                              int N, int D, void* ws, hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: return normalize_bwd_t<float>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
+        case FASTMAX_BF16: return normalize_bwd_t<bf16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
+        case FASTMAX_F16: return normalize_bwd_t<f16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+}  // namespace fastmax

@@ -118,6 +118,39 @@ def normalize(x):
     return y, inv
 
 
+def normalize_cast(x):
+    """linearmax prologue written in x's own dtype (training route): -> (y like x, contiguous; inv_norm (B,H) float32),
+    or None when the head size is not a whole number of 16-byte pieces (caller falls back to normalize())."""
+    L = _lib.lib()
+    dev = x.device
+    B, H, N, D = x.shape
+    y = torch.empty((B, H, N, D), dtype=x.dtype, device=dev)
+    inv = torch.empty((B, H), dtype=torch.float32, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_workspace(B, H), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_normalize_cast(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H, N, D,
+                                          wsp, wsb.numel(), _stream(dev))
+    if rc == _lib.E_BAD_SHAPE:
+        return None
+    _lib.check(rc, "fastmax_hip_normalize_cast")
+    return y, inv
+
+
+def normalize_backward(x, gy, inv):
+    """gradient of normalize_cast wrt x; gy like x (made contiguous), inv from the forward."""
+    L = _lib.lib()
+    dev = x.device
+    B, H, N, D = x.shape
+    gy = gy.to(x.dtype).contiguous()
+    gx = torch.empty((B, H, N, D), dtype=x.dtype, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_backward_workspace(B, H, N), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_normalize_backward(x.data_ptr(), _strides(x), _DT[x.dtype], gy.data_ptr(), inv.data_ptr(),
+                                              gx.data_ptr(), B, H, N, D, wsp, wsb.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_normalize_backward")
+    return gx
+
+
 def normalize_stats(x):
     """1 / max_n ||x_n - mean_D x_n|| per (b,h) -- the only global quantity of the linearmax prologue."""
     L = _lib.lib()

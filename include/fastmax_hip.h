@@ -109,6 +109,20 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
                                 int B, int H, int N, int D, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
+/*      training route: y = (x - mean_D x) / max-norm written in the INPUT dtype (contiguous (B,H,N,D)) -- the reference
+ *      keeps 16-bit tensors 16-bit between the prologue and the attention (fastmax_hack.py:38-43) -- plus inv_norm (B,H).
+ *      workspace: fastmax_hip_normalize_workspace(B, H).  FASTMAX_E_BAD_SHAPE when D is not a multiple of 16 bytes
+ *      of elements (the caller then uses fastmax_hip_normalize).                                                   */
+int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm,
+                               int B, int H, int N, int D, void* workspace, size_t workspace_bytes, void* stream);
+/*      backward of the prologue (the reference gets it from autograd over fastmax_hack.py:38-43):
+ *      grad_x = d/dx of y given grad_y; grad_y, grad_x contiguous (B,H,N,D) in `dtype`; x and inv_norm as in the forward.
+ *      The max-norm term goes to the first token that attains the maximum (torch.argmax).  Bitwise reproducible.  */
+size_t fastmax_hip_normalize_backward_workspace(int B, int H, int N);
+int fastmax_hip_normalize_backward(const void* x, const int64_t* x_strides, int dtype, const void* grad_y,
+                                   const float* inv_norm, void* grad_x, int B, int H, int N, int D,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused linearmax forward: fastmax_hack.py:36-60 (masked branch) in one pass over Q, K, V --
  *      the mean-centre / max-norm prologue is applied to the Q and K rows as they are staged, with the
  *      per-(b,h) scales from fastmax_hip_normalize_stats; then first-order masked fastmax with nt = 1

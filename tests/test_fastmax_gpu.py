@@ -536,3 +536,35 @@ print("narrow ok")
     env = dict(os.environ, FASTMAX_QUAD32="0", FASTMAX_QUAD32_BWD="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "narrow ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("shape", [(2, 3, 300, 64), (1, 2, 1000, 128), (1, 5, 17, 16), (1, 2, 260, 40), (2, 8, 513, 32)])
+def test_linearmax_prologue_forward_backward_kernels(shape, dt, tol):
+    """_NormalizeQK (fastmax_normalize.hip; D=40 in 16-bit takes the float32 kernel + tensor-op backward) against float64
+    autograd over the reference's own formulation (fastmax_hack.py:38-43)"""
+    from fastmax_experiments_amd.attention_mechanisms.fastmax_hack import _NormalizeQK
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(shape, generator=g).to(dt)
+    gy = torch.randn(shape, generator=g).to(dt)
+    xr = x.double().requires_grad_(True)
+    xc = xr - xr.mean(-1, keepdim=True)
+    yr = xc / torch.linalg.norm(xc, dim=-1).max(dim=-1).values[..., None, None]
+    yr.backward(gy.double())
+    xx = x.cuda().requires_grad_(True)
+    y = _NormalizeQK.apply(xx)
+    assert y.dtype == dt
+    y.backward(gy.cuda())
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().numpy()) < tol
+    assert xx.grad.dtype == dt
+    assert rel_err(xx.grad.float().cpu().numpy(), xr.grad.numpy()) < tol
+
+
+def test_linearmax_prologue_backward_is_reproducible():
+    from fastmax_experiments_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 2048, 64, generator=g).cuda()
+    gy = torch.randn(2, 4, 2048, 64, generator=g).cuda()
+    _, inv = ops.normalize_cast(x)
+    a, b = ops.normalize_backward(x, gy, inv), ops.normalize_backward(x, gy, inv)
+    assert torch.equal(a, b)

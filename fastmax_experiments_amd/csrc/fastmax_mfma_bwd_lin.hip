@@ -41,14 +41,14 @@ template <int DP> __device__ __forceinline__ void publish_state(char* smem, int 
 // dQ: grid = B*H, block = 256
 // ------------------------------------------------------------------------------------------------
 template <int DP, typename TIN>
-__global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
     constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
     constexpr int KSUM = S2I + 2 * SIMG;
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
     constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256;
-    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16;
+    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;     // NSL state row slabs (16 rows) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,9 +80,11 @@ __global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
     };
     for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
     if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
-    f32x4 s2acc[DT];                                             // S2[m = 16w + r][d = 16dt + 4q4 + reg]
+    f32x4 s2acc[NSL][DT];                                        // S2[m = 16(w + 4sl) + r][d = 16dt + 4q4 + reg]
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) s2acc[dt] = f32x4{0, 0, 0, 0};
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) s2acc[sl][dt] = f32x4{0, 0, 0, 0};
 
     const int nchunks = (N + C - 1) / C;
     issue(0);
@@ -190,22 +192,28 @@ __global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
         // ---- phase B: S2[m = 16w + r][d] += sum_j K[j][m] V[j][d]  (rows d in registers) --------------
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            Frag<NP> kf;
+            Frag<NP> kf[NSL];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) kf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * w, lane);
+            for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) kf[sl].p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * (w + 4 * sl), lane);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 Frag<NP> vtf;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) vtf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
-                s2acc[dt] = mfma_parts<NP, NP>(vtf, kf, s2acc[dt]);
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) s2acc[sl][dt] = mfma_parts<NP, NP>(vtf, kf[sl], s2acc[sl][dt]);
             }
         }
         // dQ rows, staged in the gradient dtype through this wave's own (already consumed) G image rows
         store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
                                               lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         __syncthreads();                                             // B2
-        if (c + 1 < nchunks) publish_state<DP>(smem, S2I, SIMG, s2acc, 1.0f, 16 * w + r, q4);
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+        }
     }
 }
 
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(256, 2) void bwd_p1_dq_kernel(LinBwdParams prm) {
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 template <int DP, typename TIN>
-__global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
+__global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;
     constexpr int R1 = R2I + 2 * SIMG, RQ = R1 + 2 * DP * 4;
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
     constexpr int PARTG = RQ + 2 * DP * 4, PARTQ = PARTG + RPP * DP * 4, ES = PARTQ + RPP * DP * 4;
-    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16;
+    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,9 +266,11 @@ __global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dk
         reinterpret_cast<float*>(smem + RQ)[tid] = 0.f;
         reinterpret_cast<float*>(smem + RQ)[DP + tid] = 0.f;
     }
-    f32x4 r2acc[DT];                                             // R2[m = 16w + r][d = 16dt + 4q4 + reg]
+    f32x4 r2acc[NSL][DT];                                        // R2[m = 16(w + 4sl) + r][d = 16dt + 4q4 + reg]
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) r2acc[dt] = f32x4{0, 0, 0, 0};
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) r2acc[sl][dt] = f32x4{0, 0, 0, 0};
 
     const int nchunks = (N + C - 1) / C;
     issue((nchunks - 1) * C);
@@ -392,15 +402,18 @@ __global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dk
         // ---- phase B: R2[m = 16w + r][d] += sum_i Q[i][m] ghat[i][d] -------------------------------------
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            Frag<NP> qf;
+            Frag<NP> qf[NSL];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) qf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * w, lane);
+            for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) qf[sl].p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * (w + 4 * sl), lane);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 Frag<NP> gtf;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * dt, lane);
-                r2acc[dt] = mfma_parts<NP, NP>(gtf, qf, r2acc[dt]);
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) r2acc[sl][dt] = mfma_parts<NP, NP>(gtf, qf[sl], r2acc[sl][dt]);
             }
         }
         __syncthreads();                                             // B2
@@ -408,7 +421,10 @@ __global__ __launch_bounds__(256, InTraits<TIN>::NP == 1 ? 2 : 1) void bwd_p1_dk
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         store_tile16<DP>(smem + DP * 256 + w * (16 * DP * 4), dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
-        if (c > 0) publish_state<DP>(smem, R2I, SIMG, r2acc, a, 16 * w + r, q4);
+        if (c > 0) {
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+        }
         __syncthreads();
     }
 }
@@ -436,7 +452,8 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream)
 }
 
 bool lin_bwd_supported(const fastmax_problem& p) {
-    if (!(p.p == 1 && p.causal) || p.D > 64) return false;
+    // D <= 64 for every dtype; 64 < D <= 128 for bf16 (one operand part: the images and the D x D state fit the 160 KB LDS)
+    if (!(p.p == 1 && p.causal) || p.D > 128 || (p.D > 64 && p.in_dtype != FASTMAX_BF16)) return false;
     const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
     // linear time pays off once the O(N^2) tiles outgrow the carried-state work
     return (p.D % epl) == 0 && p.Nq >= 512;
@@ -451,7 +468,7 @@ int launch_bwd_lin(const BwdArgs& a) {
     const int BH = a.prob.B * a.prob.H;
     switch (a.prob.in_dtype) {
         case FASTMAX_F32: return launch_lin_bwd_t<64, float>(prm, BH, a.stream);
-        case FASTMAX_BF16: return launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream);
+        case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream) : launch_lin_bwd_t<128, bf16_t>(prm, BH, a.stream);
         case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t>(prm, BH, a.stream);
     }
     return FASTMAX_E_BAD_DTYPE;

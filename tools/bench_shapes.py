@@ -51,6 +51,11 @@ def main():
         ("C4 llama-2-7b heads fastmax(p=2) fwd+bwd", "fastmax", (2, 32, 4096, 128), "bf16", 2, "fwd+bwd"),
         ("C5 llama-2-7b linearmax 16k", "linearmax", (1, 32, 16384, 128), "bf16", 1, "fwd"),
         ("C5 fastmax p=1 16k (no prologue)", "fastmax", (1, 32, 16384, 128), "bf16", 1, "fwd"),
+        ("C3 linearmax fwd+bwd (training route)", "linearmax", (8, 32, 2048, 64), "bf16", 1, "fwd+bwd"),
+        ("C4 linearmax fwd+bwd", "linearmax", (2, 32, 4096, 128), "bf16", 1, "fwd+bwd"),
+        ("C5 linearmax 16k fwd+bwd", "linearmax", (1, 32, 16384, 128), "bf16", 1, "fwd+bwd"),
+        ("headline bf16 p=1 fwd+bwd", "fastmax", (16, 32, 4096, 64), "bf16", 1, "fwd+bwd"),
+        ("headline p=2 fwd+bwd f32", "fastmax", (16, 32, 4096, 64), "f32", 2, "fwd+bwd"),
     ]
     if quick:
         cases = cases[:4]

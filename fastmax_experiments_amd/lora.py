@@ -14,6 +14,7 @@ per byte with the first element in the high nibble.  Parity with bitsandbytes' o
 Fused forward (csrc/nf4_lora.hip):  y = x deq(W)^T + bias + (dropout(x) A^T) (scaling * scatter(B))^T
 """
 import ctypes
+import os
 import math
 from typing import Any, Tuple, Union
 
@@ -136,14 +137,46 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# Above this many rows of x the frozen weight is decoded ONCE into a bf16 scratch matrix (HIP kernel) and the product is a
+# plain library GEMM: the fused kernel re-decodes each W tile in every one of the M/128 workgroup rows and is
+# vector-ALU-bound there (measured 0.54-0.72 PF/s against 1.1-1.5 PF/s dense at M = 8k..16k); below it the fused kernel
+# wins on weight bytes (0.5 B/element instead of 2).  288 GB of HBM make the scratch (<= N K 2 bytes, shared by all layers) free.
+DENSE_M = int(os.environ.get("FASTMAX_NF4_DENSE_M", "2048"))
+_dense_scratch = {}
+
+
+def _dense_weight(wq, absmax, N, K):
+    """bf16 (N, K) view of a per-device scratch buffer holding the decoded weight (valid until the next call on the stream)."""
+    key = wq.device
+    buf = _dense_scratch.get(key)
+    if buf is None or buf.numel() < N * K:
+        buf = torch.empty(N * K, dtype=torch.bfloat16, device=wq.device)
+        _dense_scratch[key] = buf
+    with torch.cuda.device(wq.device):
+        rc = _lib.lib().fastmax_hip_nf4_dequantize(wq.data_ptr(), absmax.data_ptr(), buf.data_ptr(), N * K, _lib.BF16,
+                                                   _stream(wq.device))
+    _lib.check(rc, "fastmax_hip_nf4_dequantize")
+    return buf[: N * K].view(N, K)
+
+
 class _QLoRALinearFn(torch.autograd.Function):
-    """y = x deq(W)^T + bias + ea eb^T, all in one HIP kernel; dx through the dequant GEMM,
-    d(ea), d(eb) are thin library GEMMs."""
+    """y = x deq(W)^T + bias + ea eb^T.  Few rows: all in one HIP kernel (dx through the same dequant GEMM).  Many rows
+    (M >= DENSE_M, bf16): HIP dequant to scratch + library GEMMs.  d(ea), d(eb) are thin library GEMMs."""
 
     @staticmethod
     def forward(ctx, x2, ea, eb, wq, absmax, bias, N, K):
         M = x2.shape[0]
         dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
+        ctx.dense = dt == _lib.BF16 and M >= DENSE_M
+        if ctx.dense:
+            y = x2 @ _dense_weight(wq, absmax, N, K).t()
+            if ea is not None:
+                y.addmm_(ea, eb.t())
+            if bias is not None:
+                y += bias.to(y.dtype)
+            ctx.save_for_backward(ea, eb, wq, absmax)
+            ctx.dims = (M, N, K, dt)
+            return y
         y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
         with torch.cuda.device(x2.device):
             rc = _lib.lib().fastmax_hip_nf4_linear_forward(
@@ -161,7 +194,9 @@ class _QLoRALinearFn(torch.autograd.Function):
         M, N, K, dt = ctx.dims
         dy = dy.contiguous()
         dx = d_ea = d_eb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.dense:
+            dx = dy @ _dense_weight(wq, absmax, N, K)
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
             with torch.cuda.device(dy.device):
                 rc = _lib.lib().fastmax_hip_nf4_linear_backward_input(dy.data_ptr(), N, wq.data_ptr(), absmax.data_ptr(),

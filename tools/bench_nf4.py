@@ -26,7 +26,7 @@ def timeit(fn, iters=10, rounds=5):
 def main():
     print("| M (tokens) | K | N | NF4+LoRA fwd ms | TFLOP/s | dx ms | TFLOP/s | dense bf16 F.linear ms | TFLOP/s |")
     print("|---|---|---|---|---|---|---|---|---|")
-    for M, K, N in ((16384, 2048, 2560), (16384, 4096, 4096), (8192, 4096, 12288), (16384, 4096, 11008)):
+    for M, K, N in ((64, 4096, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (4096, 4096, 4096), (2048, 4096, 11008), (16384, 2048, 2560), (16384, 4096, 4096), (8192, 4096, 12288), (16384, 4096, 11008)):
         torch.manual_seed(0)
         layer = lora.LoRALinear(K, N, r=8, lora_alpha=16, bias=False)
         torch.nn.init.normal_(layer.lora_B, std=0.02)

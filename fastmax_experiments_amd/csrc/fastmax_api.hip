@@ -103,7 +103,8 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
 
 size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
-    return bwd_quadratic_workspace(*prob);
+    const size_t a = bwd_quadratic_workspace(*prob), b = lin_bwd_workspace(*prob);
+    return a > b ? a : b;
 }
 
 int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,

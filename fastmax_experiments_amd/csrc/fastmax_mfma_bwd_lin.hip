@@ -22,6 +22,10 @@ struct LinBwdParams {
     float* c;                       // workspace (B,H,N)
     int H, N, D, grad_dtype, o_dtype;
     float a;
+    // sequence split for few heads (fastmax_mfma_split.hip): segment s of the dQ scan starts from fstate record s-1
+    // (sums over the earlier segments), segment s of the dK/dV scan from rstate record s (sums over the later ones)
+    const float *fstate, *rstate;
+    int nseg, cps;
 };
 
 template <int DP> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[DP / 16],
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
@@ -87,9 +91,22 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         for (int dt = 0; dt < DT; ++dt) s2acc[sl][dt] = f32x4{0, 0, 0, 0};
 
     const int nchunks = (N + C - 1) / C;
-    issue(0);
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+    if (seg > 0) {
+        __syncthreads();                                             // zero fill done before the images are overwritten
+        const float* rec = prm.fstate + ((int64_t)bh * (prm.nseg - 1) + (seg - 1)) * (DP * DP + 2 * DP);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                s2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
+            publish_state<DP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+        }
+        if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[DP * (c_begin & 1) + tid] = rec[DP * DP + DP + tid];
+    }
+    issue(c_begin * C);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         const int n0 = c * C, cur = c & 1, nxt = cur ^ 1;
         const float* ksum_cur = reinterpret_cast<const float*>(smem + KSUM) + DP * cur;
         {
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
 #pragma unroll
             for (int e = 0; e < EPL; ++e) reinterpret_cast<float*>(smem + PARTK)[srow * DP + scol * EPL + e] = ck[e];
         }
-        if (c + 1 < nchunks) issue(n0 + C);
+        if (c + 1 < c_end) issue(n0 + C);
         __syncthreads();                                             // B1
         if (tid < DP) {
             float s = ksum_cur[tid];
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
                                               lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         __syncthreads();                                             // B2
-        if (c + 1 < nchunks) {
+        if (c + 1 < c_end) {
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
         }
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const float a = prm.a;
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)h * prm.qs.sh;
@@ -273,9 +290,26 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
         for (int dt = 0; dt < DT; ++dt) r2acc[sl][dt] = f32x4{0, 0, 0, 0};
 
     const int nchunks = (N + C - 1) / C;
-    issue((nchunks - 1) * C);
+    const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
+    if (seg + 1 < prm.nseg) {
+        __syncthreads();
+        const float* rec = prm.rstate + ((int64_t)bh * (prm.nseg - 1) + seg) * (DP * DP + 2 * DP);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                r2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
+            publish_state<DP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+        }
+        if (tid < DP) {
+            const int par = (c_end - 1) & 1;
+            reinterpret_cast<float*>(smem + R1)[DP * par + tid] = rec[DP * DP + tid];
+            reinterpret_cast<float*>(smem + RQ)[DP * par + tid] = a * rec[DP * DP + DP + tid];
+        }
+    }
+    issue((c_end - 1) * C);
     __syncthreads();
-    for (int c = nchunks - 1; c >= 0; --c) {
+    for (int c = c_end - 1; c >= c_begin; --c) {
         const int n0 = c * C, cur = c & 1, nxt = cur ^ 1;
         const float* r1_cur = reinterpret_cast<const float*>(smem + R1) + DP * cur;
         const float* rq_cur = reinterpret_cast<const float*>(smem + RQ) + DP * cur;
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
                 reinterpret_cast<float*>(smem + PARTQ)[srow * DP + scol * EPL + e] = cq[e];
             }
         }
-        if (c > 0) issue(n0 - C);
+        if (c > c_begin) issue(n0 - C);
         __syncthreads();                                             // B1
         for (int t = tid; t < 2 * DP; t += 256) {                    // suffix sums for the next (earlier) chunk
             const int col = t % DP;
@@ -421,7 +455,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         store_tile16<DP>(smem + DP * 256 + w * (16 * DP * 4), dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
-        if (c > 0) {
+        if (c > c_begin) {
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
         }
@@ -430,7 +464,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
 }
 
 template <int DP, typename TIN>
-static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream) {
+static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
     constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
     constexpr int lds_q = 3 * NP * IMG + 2 * SIMG + 2 * DP * 4 + RPP * DP * 4 + 512;
@@ -446,9 +480,23 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream)
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kq, dim3(BH), dim3(256), lds_q, stream, prm);
-    hipLaunchKernelGGL(kkv, dim3(BH), dim3(256), lds_kv, stream, prm);
+    hipLaunchKernelGGL(kq, dim3(BH * prm.nseg), dim3(256), lds_q, stream, prm);
+    if (prm.nseg > 1) {
+        const int rc = launch_split_rstates(prm.q, prm.qs, prm.go, prm.gos, prm.g, prm.c, const_cast<float*>(prm.rstate), prob,
+                                            SplitPlan{prm.nseg, prm.cps}, DP, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(256), lds_kv, stream, prm);
     return (int)hipGetLastError();
+}
+
+bool lin_bwd_supported(const fastmax_problem& p);
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// workspace = [ c (B,H,N) | forward-scan states | reverse-scan states ]   (the states only when the sequence is split)
+size_t lin_bwd_workspace(const fastmax_problem& p) {
+    size_t bytes = align16(sizeof(float) * (size_t)p.B * p.H * p.Nq);
+    if (lin_bwd_supported(p)) bytes += 2 * align16(split_workspace_bytes(p, p.D <= 64 ? 64 : 128));
+    return bytes;
 }
 
 bool lin_bwd_supported(const fastmax_problem& p) {
@@ -461,15 +509,29 @@ bool lin_bwd_supported(const fastmax_problem& p) {
 
 int launch_bwd_lin(const BwdArgs& a) {
     if (!lin_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
-    if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;
+    if (a.workspace_bytes < lin_bwd_workspace(a.prob) || !a.workspace) return FASTMAX_E_WORKSPACE;
+    const int dp = a.prob.D <= 64 ? 64 : 128;
+    const SplitPlan plan = split_plan(a.prob);
+    char* ws = reinterpret_cast<char*>(a.workspace);
+    float* cbuf = reinterpret_cast<float*>(ws);
+    const size_t coff = align16(sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq), sbytes = align16(split_workspace_bytes(a.prob, dp));
+    float* fstate = reinterpret_cast<float*>(ws + coff);
+    float* rstate = reinterpret_cast<float*>(ws + coff + sbytes);
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
-                     reinterpret_cast<float*>(a.workspace), a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype,
-                     a.prob.out_dtype, a.prob.a};
+                     cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
+                     fstate, rstate, plan.nseg, plan.cps};
     const int BH = a.prob.B * a.prob.H;
+    if (plan.nseg > 1) {
+        // forward-scan states (sum k v^T, sum k) exactly as the forward's; the reverse-scan states need c_i, which the dQ
+        // kernel writes, so they are computed between the two main kernels
+        FwdArgs fa{a.prob, a.q, a.k, a.v, a.qs, a.ks, a.vs, nullptr, nullptr, fstate, sbytes, a.stream};
+        const int rc = launch_split_states(fa, plan, dp, nullptr);
+        if (rc) return rc;
+    }
     switch (a.prob.in_dtype) {
-        case FASTMAX_F32: return launch_lin_bwd_t<64, float>(prm, BH, a.stream);
-        case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream) : launch_lin_bwd_t<128, bf16_t>(prm, BH, a.stream);
-        case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t>(prm, BH, a.stream);
+        case FASTMAX_F32: return launch_lin_bwd_t<64, float>(prm, BH, a.stream, a.prob);
+        case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream, a.prob) : launch_lin_bwd_t<128, bf16_t>(prm, BH, a.stream, a.prob);
+        case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t>(prm, BH, a.stream, a.prob);
     }
     return FASTMAX_E_BAD_DTYPE;
 }

@@ -16,9 +16,13 @@ struct StateParams {
     float* state;
     const float* kscale;      // fused linearmax: K rows are (k - mean) * kscale[bh]
     int H, N, D, nseg, cps;
+    const float *g, *c;       // RS (reverse states for the backward): k = q, v = grad_o, rows of v scaled by w_i = 1/g_i,
+                              // "ksum" weighted by e_i = -w_i c_i
 };
 
-template <int DP, typename TIN, bool NORM>
+// RS = false: forward states of segments 0 .. nseg-2 (record seg).  RS = true: the reverse-scan states of the p=1 backward
+// (fastmax_mfma_bwd_lin.hip) of segments 1 .. nseg-1 (record seg-1): R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e.
+template <int DP, typename TIN, bool NORM, bool RS = false>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StateParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2;
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int seg = blockIdx.x, bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int seg = blockIdx.x + (RS ? 1 : 0), bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
@@ -67,6 +71,18 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
             float xk[EPL], xv[EPL];
             piece_to_float<TIN>(rk[ps], xk);
             piece_to_float<TIN>(rv[ps], xv);
+            if constexpr (RS) {
+                const int gi = n0 + row, gc = gi < N ? gi : N - 1;
+                const float wi = gi < N ? 1.0f / prm.g[(int64_t)bh * N + gc] : 0.f;
+                const float ei = -wi * prm.c[(int64_t)bh * N + gc];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) xv[e] *= wi;
+                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                stage_floats<DP, EPL, NP>(smem, VI, row, scol, xv);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { ck[e] = fmaf(xk[e], ei, ck[e]); cv[e] += xv[e]; }
+                continue;
+            }
             if constexpr (NORM) {
                 float sk = 0.f;
 #pragma unroll
@@ -103,7 +119,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
         }
     }
     // record = [S2 (DP x DP, row-major [m][d]) | S1 (DP) | ksum (DP)]
-    float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg) * (DP * DP + 2 * DP);
+    float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg - (RS ? 1 : 0)) * (DP * DP + 2 * DP);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         reinterpret_cast<float*>(smem + PARTK)[srow * DP + scol * EPL + e] = ck[e];
@@ -125,13 +141,14 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
     }
 }
 
-// inclusive prefix over the nseg-1 records of one head; grid = (ceil(REC/256), B*H)
-__global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int nrec, int rec_floats) {
+// inclusive prefix (reverse = 1: suffix) over the nseg-1 records of one head; grid = (ceil(REC/256), B*H)
+__global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int nrec, int rec_floats, int reverse) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= rec_floats) return;
     float* base = state + (int64_t)blockIdx.y * nrec * rec_floats + e;
     float acc = 0.f;
-    for (int s = 0; s < nrec; ++s) {
+    for (int i = 0; i < nrec; ++i) {
+        const int s = reverse ? nrec - 1 - i : i;
         acc += base[(int64_t)s * rec_floats];
         base[(int64_t)s * rec_floats] = acc;
     }
@@ -155,11 +172,11 @@ size_t split_workspace_bytes(const fastmax_problem& p, int dp) {
     return sizeof(float) * (size_t)p.B * p.H * (plan.nseg - 1) * ((size_t)dp * dp + 2 * dp);
 }
 
-template <int DP, typename TIN, bool NORM>
+template <int DP, typename TIN, bool NORM, bool RS = false>
 static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
     constexpr int lds = 2 * NP * 64 * DP * 2 + 2 * RPP * DP * 4;
-    auto kern = p1_state_kernel<DP, TIN, NORM>;
+    auto kern = p1_state_kernel<DP, TIN, NORM, RS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -168,7 +185,7 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(256), lds, stream, prm);
     const int rec = DP * DP + 2 * DP;
-    hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec);
+    hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec, RS ? 1 : 0);
     return (int)hipGetLastError();
 }
 template <typename TIN, bool NORM>
@@ -178,9 +195,22 @@ static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t st
     else return launch_state_t<128, TIN, NORM>(prm, BH, stream);
 }
 
+// reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
+int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
+                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream) {
+    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c};
+    const int BH = p.B * p.H;
+    switch (p.in_dtype) {
+        case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, false, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+        case FASTMAX_BF16: return dp == 64 ? launch_state_t<64, bf16_t, false, true>(prm, BH, stream) : launch_state_t<128, bf16_t, false, true>(prm, BH, stream);
+        case FASTMAX_F16: return dp == 64 ? launch_state_t<64, f16_t, false, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale) {
     StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), kscale, a.prob.H, a.prob.Nq, a.prob.D,
-                    plan.nseg, plan.cps};
+                    plan.nseg, plan.cps, nullptr, nullptr};
     const int BH = a.prob.B * a.prob.H;
     const bool norm = kscale != nullptr;
     switch (a.prob.in_dtype) {

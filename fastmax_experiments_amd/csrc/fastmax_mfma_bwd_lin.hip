@@ -28,16 +28,22 @@ struct LinBwdParams {
     int nseg, cps;
 };
 
-template <int DP> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[DP / 16],
+// State images (S2 for dQ, a R2 for dK/dV): hi + lo bf16 parts for fp32 / fp16 problems, ONE rounded part for bf16
+// problems (SP = 1) -- as in the forward kernel its rounding is far below the bf16 rounding of the gradients.
+template <int DP, int SP = 2> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[DP / 16],
                                                                   float scale, int row, int q4) {
-    // accumulators (rows = 16t + 4q4 + reg, column = `row` on the lane) -> bf16 hi/lo image row `row`
+    // accumulators (rows = 16t + 4q4 + reg, column = `row` on the lane) -> bf16 image row `row`
 #pragma unroll
     for (int t = 0; t < DP / 16; ++t) {
-        bf16x4 hi, lo;
-        split4(acc[t] * scale, hi, lo);
         const int off = img_off<DP>(row, 2 * t + (q4 >> 1)) + ((q4 & 1) << 3);
-        *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
-        *reinterpret_cast<bf16x4*>(smem + base + simg + off) = lo;
+        if constexpr (SP == 1) {
+            *reinterpret_cast<bf16x4*>(smem + base + off) = to_bf16x4(acc[t] * scale);
+        } else {
+            bf16x4 hi, lo;
+            split4(acc[t] * scale, hi, lo);
+            *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
+            *reinterpret_cast<bf16x4*>(smem + base + simg + off) = lo;
+        }
     }
 }
 
@@ -47,9 +53,9 @@ template <int DP> __device__ __forceinline__ void publish_state(char* smem, int 
 template <int DP, typename TIN>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
-    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
+    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
-    constexpr int KSUM = S2I + 2 * SIMG;
+    constexpr int KSUM = S2I + SP * SIMG;
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
     constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256;
     constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;     // NSL state row slabs (16 rows) per wave
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
         }
     };
-    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < (SP * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
     if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
     f32x4 s2acc[NSL][DT];                                        // S2[m = 16(w + 4sl) + r][d = 16dt + 4q4 + reg]
 #pragma unroll
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 s2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
-            publish_state<DP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+            publish_state<DP, SP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
         }
         if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[DP * (c_begin & 1) + tid] = rec[DP * DP + DP + tid];
     }
@@ -159,10 +165,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
             acc[mt] = *reinterpret_cast<const f32x4*>(ksum_cur + 16 * mt + 4 * q4) * (-ci);     // ksum_prev * (-c_i)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag<2> sf;
-                sf.p[0] = *reinterpret_cast<const bf16x8*>(smem + S2I + img_off<DP>(16 * mt + r, 4 * ks + q4));
-                sf.p[1] = *reinterpret_cast<const bf16x8*>(smem + S2I + SIMG + img_off<DP>(16 * mt + r, 4 * ks + q4));
-                acc[mt] = mfma_parts<2, NP>(sf, gf[ks], acc[mt]);                                  // S2_prev G_i
+                Frag<SP> sf;
+#pragma unroll
+                for (int p = 0; p < SP; ++p) sf.p[p] = *reinterpret_cast<const bf16x8*>(smem + S2I + p * SIMG + img_off<DP>(16 * mt + r, 4 * ks + q4));
+                acc[mt] = mfma_parts<SP, NP>(sf, gf[ks], acc[mt]);                                  // S2_prev G_i
             }
         }
         Frag<2> tf[2];
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         __syncthreads();                                             // B2
         if (c + 1 < c_end) {
 #pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
         }
     }
 }
@@ -240,9 +246,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
 template <int DP, typename TIN>
 __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
-    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2;
+    constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;
-    constexpr int R1 = R2I + 2 * SIMG, RQ = R1 + 2 * DP * 4;
+    constexpr int R1 = R2I + SP * SIMG, RQ = R1 + 2 * DP * 4;
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
     constexpr int PARTG = RQ + 2 * DP * 4, PARTQ = PARTG + RPP * DP * 4, ES = PARTQ + RPP * DP * 4;
     constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
             rc[ps] = prm.c[(int64_t)bh * N + rcl];
         }
     };
-    for (int i = tid; i < (2 * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + R2I + 16 * i) = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < (SP * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + R2I + 16 * i) = f32x4{0, 0, 0, 0};
     if (tid < DP) {
         reinterpret_cast<float*>(smem + R1)[tid] = 0.f;          // parity buffers are indexed by (chunk & 1)
         reinterpret_cast<float*>(smem + R1)[DP + tid] = 0.f;
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 r2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
-            publish_state<DP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+            publish_state<DP, SP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
         }
         if (tid < DP) {
             const int par = (c_end - 1) & 1;
@@ -369,16 +375,17 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
             dvacc[t] = *reinterpret_cast<const f32x4*>(r1_cur + 16 * t + 4 * q4);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag<2> rf, rtf;
-                rf.p[0] = *reinterpret_cast<const bf16x8*>(smem + R2I + img_off<DP>(16 * t + r, 4 * ks + q4));
-                rf.p[1] = *reinterpret_cast<const bf16x8*>(smem + R2I + SIMG + img_off<DP>(16 * t + r, 4 * ks + q4));
-                dkacc[t] = mfma_parts<2, NP>(rf, vf[ks], dkacc[t]);
-                rtf.p[0] = ld_tr8<DP>(smem, R2I, 32 * ks, 16 * t, lane);                   // A[row d][k = m], permuted k
-                rtf.p[1] = ld_tr8<DP>(smem, R2I + SIMG, 32 * ks, 16 * t, lane);
+                Frag<SP> rf, rtf;
+#pragma unroll
+                for (int p = 0; p < SP; ++p) {
+                    rf.p[p] = *reinterpret_cast<const bf16x8*>(smem + R2I + p * SIMG + img_off<DP>(16 * t + r, 4 * ks + q4));
+                    rtf.p[p] = ld_tr8<DP>(smem, R2I + p * SIMG, 32 * ks, 16 * t, lane);     // A[row d][k = m], permuted k
+                }
+                dkacc[t] = mfma_parts<SP, NP>(rf, vf[ks], dkacc[t]);
                 Frag<NP> kpf;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) kpf.p[p] = ld_row8_perm<DP>(smem, KI + p * IMG, kj, 32 * ks, q4);
-                dvacc[t] = mfma_parts<2, NP>(rtf, kpf, dvacc[t]);
+                dvacc[t] = mfma_parts<SP, NP>(rtf, kpf, dvacc[t]);
             }
         }
         Frag<2> tf[2], pf[2];
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
                          ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
         if (c > c_begin) {
 #pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) publish_state<DP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
         }
         __syncthreads();
     }
@@ -467,8 +474,8 @@ template <int DP, typename TIN>
 static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
     constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
-    constexpr int lds_q = 3 * NP * IMG + 2 * SIMG + 2 * DP * 4 + RPP * DP * 4 + 512;
-    constexpr int lds_kv = 4 * NP * IMG + 2 * SIMG + 4 * DP * 4 + 2 * RPP * DP * 4 + 256;
+    constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPP * DP * 4 + 512;
+    constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPP * DP * 4 + 256;
     static_assert(lds_kv <= 160 * 1024, "LDS budget");
     auto kq = bwd_p1_dq_kernel<DP, TIN>;
     auto kkv = bwd_p1_dkv_kernel<DP, TIN>;

@@ -107,11 +107,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the fastmax operator has no CPU fallback")
+    # FASTMAX_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, barriers / MAX over gloo on the host); the measured runs use RCCL with one GPU per rank
+    backend = os.environ.get("FASTMAX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL on ROCm; used for the barriers only
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL on ROCm; used for the barriers only
 
     from attention_mechanisms.fastmax import fastmax
     from attention_mechanisms.fastmax_hack import fastmax_hack
@@ -157,7 +165,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # mean device-side duration of one launch of the hot kernel (HIP events on the launch stream)

@@ -8,6 +8,8 @@
 // Cost: K and V of all but the last segment are read twice (+ <= 50 % of the K,V bytes, 0 when nseg = 1).
 #include "fastmax_mfma_common.h"
 
+#include <cstdlib>
+
 namespace fastmax {
 
 struct StateParams {
@@ -155,9 +157,11 @@ __global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int 
 }
 
 SplitPlan split_plan(const fastmax_problem& p) {
+    // aim at `target` workgroups (two per CU); FASTMAX_SPLIT_TARGET overrides for experiments
+    static const int target = [] { const char* e = getenv("FASTMAX_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
     const int BH = p.B * p.H, nchunks = (p.Nq + 63) / 64;
-    if (BH >= 384 || nchunks < 8) return SplitPlan{1, nchunks};
-    int nseg = (512 + BH - 1) / BH;
+    if (BH >= target * 3 / 4 || nchunks < 8) return SplitPlan{1, nchunks};
+    int nseg = (target + BH - 1) / BH;
     if (nseg > nchunks / 4) nseg = nchunks / 4;                  // at least 4 chunks per segment
     if (nseg > 32) nseg = 32;
     if (nseg < 2) return SplitPlan{1, nchunks};

@@ -28,19 +28,41 @@ struct LinBwdParams {
     int nseg, cps;
 };
 
+// Stage a wave's 16 x W fp32 accumulator tile (lane = row r, acc[t][reg] = column 16t + 4q4 + reg) through a wave-private
+// 16*W*4-byte LDS area and write it out as whole row segments at columns [col0, col0 + W) of the output rows.
+template <int W>
+__device__ __forceinline__ void store_cols16(char* ost, const f32x4 (&acc)[W / 16], float scale, int lane, void* out, int dtype,
+                                             int64_t row0_elem, int col0, int first_row, int nrows, int D) {
+    constexpr int C16 = W / 4, T = W / 16;
+    const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int c16 = 4 * t + q4;
+        *reinterpret_cast<f32x4*>(ost + r * (W * 4) + (((c16 ^ r) & (C16 - 1)) << 4)) = acc[t] * scale;
+    }
+#pragma unroll
+    for (int u = 0; u < (16 * C16) / 64; ++u) {
+        const int idx = u * 64 + lane, rl = idx / C16, c16 = idx % C16;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ost + rl * (W * 4) + (((c16 ^ rl) & (C16 - 1)) << 4));
+        if (first_row + rl < nrows && col0 + 4 * c16 < D)
+            store4_any(out, dtype, row0_elem + (int64_t)rl * D + col0 + 4 * c16, val);
+    }
+}
+
 // State images (S2 for dQ, a R2 for dK/dV): hi + lo bf16 parts for fp32 / fp16 problems, ONE rounded part for bf16
 // problems (SP = 1) -- as in the forward kernel its rounding is far below the bf16 rounding of the gradients.
-template <int DP, int SP = 2> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[DP / 16],
-                                                                  float scale, int row, int q4) {
-    // accumulators (rows = 16t + 4q4 + reg, column = `row` on the lane) -> bf16 image row `row`
+template <int DP, int SP, int TW> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[TW],
+                                                                  float scale, int row, int q4, int t0) {
+    // accumulators (rows = 16(t0+t) + 4q4 + reg, column = `row` on the lane) -> bf16 image row `row`
 #pragma unroll
-    for (int t = 0; t < DP / 16; ++t) {
+    for (int tt = 0; tt < TW; ++tt) {
+        const int t = t0 + tt;
         const int off = img_off<DP>(row, 2 * t + (q4 >> 1)) + ((q4 & 1) << 3);
         if constexpr (SP == 1) {
-            *reinterpret_cast<bf16x4*>(smem + base + off) = to_bf16x4(acc[t] * scale);
+            *reinterpret_cast<bf16x4*>(smem + base + off) = to_bf16x4(acc[tt] * scale);
         } else {
             bf16x4 hi, lo;
-            split4(acc[t] * scale, hi, lo);
+            split4(acc[tt] * scale, hi, lo);
             *reinterpret_cast<bf16x4*>(smem + base + off) = hi;
             *reinterpret_cast<bf16x4*>(smem + base + simg + off) = lo;
         }
@@ -50,18 +72,24 @@ template <int DP, int SP = 2> __device__ __forceinline__ void publish_state(char
 // ------------------------------------------------------------------------------------------------
 // dQ: grid = B*H, block = 256
 // ------------------------------------------------------------------------------------------------
-template <int DP, typename TIN>
-__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
+// NW = 4: wave w owns query tile w and every output column.  NW = 8 (the variants whose LDS footprint allows one workgroup
+// per CU only): wave (wq = w & 3, hf = w >> 2) owns query tile wq and the column half hf of dQ and of the S2 state; the
+// 64 x 64 score-shaped tile is computed by both halves.
+template <int DP, typename TIN, int NW>
+__global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
     constexpr int KSUM = S2I + SP * SIMG;
-    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
-    constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256;
-    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;     // NSL state row slabs (16 rows) per wave
+    constexpr int NT = 64 * NW, HF = NW / 4;
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = C / RPP;
+    constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256, OST = WS + 256;
+    constexpr int KS = DP / 32, NSL = DP / 64;     // NSL state row slabs (16 rows) per wave
+    constexpr int MT = (DP / 16) / HF, DT = (DP / 16) / HF;                  // column tiles of this wave (dQ columns m, S2 columns d)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = w & 3, hf = w >> 2, t0 = hf * MT;
     const int r = lane & 15, q4 = lane >> 4;
     const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
@@ -88,7 +116,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
             rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
         }
     };
-    for (int i = tid; i < (SP * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < (SP * SIMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
     if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[tid] = 0.f;
     f32x4 s2acc[NSL][DT];                                        // S2[m = 16(w + 4sl) + r][d = 16dt + 4q4 + reg]
 #pragma unroll
@@ -105,8 +133,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                s2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
-            publish_state<DP, SP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+                s2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (wq + 4 * sl) + r) * DP + 16 * (t0 + dt) + 4 * q4);
+            publish_state<DP, SP, DT>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (wq + 4 * sl) + r, q4, t0);
         }
         if (tid < DP) reinterpret_cast<float*>(smem + KSUM)[DP * (c_begin & 1) + tid] = rec[DP * DP + DP + tid];
     }
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
             reinterpret_cast<float*>(smem + KSUM)[DP * nxt + tid] = s;
         }
         // ---- phase A: dQ^T[m][i] for this wave's 16 queries ------------------------------------------
-        const int qi = 16 * w + r;
+        const int qi = 16 * wq + r;
         const float ci = reinterpret_cast<const float*>(smem + CS)[qi];
         const float wi = reinterpret_cast<const float*>(smem + WS)[qi];
         Frag<NP> gf[KS];
@@ -162,12 +190,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            acc[mt] = *reinterpret_cast<const f32x4*>(ksum_cur + 16 * mt + 4 * q4) * (-ci);     // ksum_prev * (-c_i)
+            acc[mt] = *reinterpret_cast<const f32x4*>(ksum_cur + 16 * (t0 + mt) + 4 * q4) * (-ci);     // ksum_prev * (-c_i)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag<SP> sf;
 #pragma unroll
-                for (int p = 0; p < SP; ++p) sf.p[p] = *reinterpret_cast<const bf16x8*>(smem + S2I + p * SIMG + img_off<DP>(16 * mt + r, 4 * ks + q4));
+                for (int p = 0; p < SP; ++p) sf.p[p] = *reinterpret_cast<const bf16x8*>(smem + S2I + p * SIMG + img_off<DP>(16 * (t0 + mt) + r, 4 * ks + q4));
                 acc[mt] = mfma_parts<SP, NP>(sf, gf[ks], acc[mt]);                                  // S2_prev G_i
             }
         }
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
             for (int e = 0; e < 2; ++e) {
                 const int jt = 2 * s + e;
                 f32x4 u = {-ci, -ci, -ci, -ci};
-                if (jt <= w) {
+                if (jt <= wq) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> vf;
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool keep = (jt < w) || (jt == w && (4 * q4 + i) <= r);
+                    const bool keep = (jt < wq) || (jt == wq && (4 * q4 + i) <= r);
                     tt[e][i] = keep ? u[i] : 0.f;
                 }
             }
@@ -202,12 +230,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (2 * s <= w) {
+            if (2 * s <= wq) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     Frag<NP> ktf;
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * mt, lane);
+                    for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * (t0 + mt), lane);
                     acc[mt] = mfma_parts<NP, 2>(ktf, tf[s], acc[mt]);
                 }
             }
@@ -219,23 +247,28 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) kf[sl].p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * (w + 4 * sl), lane);
+                for (int p = 0; p < NP; ++p) kf[sl].p[p] = ld_tr8<DP>(smem, KI + p * IMG, 32 * s, 16 * (wq + 4 * sl), lane);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 Frag<NP> vtf;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) vtf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * dt, lane);
+                for (int p = 0; p < NP; ++p) vtf.p[p] = ld_tr8<DP>(smem, VI + p * IMG, 32 * s, 16 * (t0 + dt), lane);
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) s2acc[sl][dt] = mfma_parts<NP, NP>(vtf, kf[sl], s2acc[sl][dt]);
             }
         }
-        // dQ rows, staged in the gradient dtype through this wave's own (already consumed) G image rows
-        store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
-                                              lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        if constexpr (NW == 4) {
+            // dQ rows, staged in the gradient dtype through this wave's own (already consumed) G image rows
+            store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
+                                                  lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        } else {
+            store_cols16<16 * MT>(smem + OST + w * (16 * 16 * MT * 4), acc, prm.a * wi, lane, prm.dq, prm.grad_dtype,
+                                  ((int64_t)bh * N + n0 + 16 * wq) * D, 16 * t0, n0 + 16 * wq, N, D);
+        }
         __syncthreads();                                             // B2
         if (c + 1 < c_end) {
 #pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (w + 4 * sl) + r, q4);
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP, DT>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (wq + 4 * sl) + r, q4, t0);
         }
     }
 }
@@ -243,18 +276,22 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd_p1_dq_kernel(LinBwd
 // ------------------------------------------------------------------------------------------------
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
-template <int DP, typename TIN>
-__global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
+// NW = 8: wave (wk = w & 3, hf = w >> 2) owns the 16 keys of tile wk and the column half hf of dK, dV and of the R2 state
+template <int DP, typename TIN, int NW>
+__global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;
     constexpr int R1 = R2I + SP * SIMG, RQ = R1 + 2 * DP * 4;
-    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int NT = 64 * NW, HF = NW / 4;
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = C / RPP;
     constexpr int PARTG = RQ + 2 * DP * 4, PARTQ = PARTG + RPP * DP * 4, ES = PARTQ + RPP * DP * 4;
-    constexpr int KS = DP / 32, MT = DP / 16, DT = DP / 16, NSL = DP / 64;
+    constexpr int KS = DP / 32, NSL = DP / 64;
+    constexpr int MT = (DP / 16) / HF, DT = (DP / 16) / HF;                  // column tiles of this wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = w & 3, hf = w >> 2, t0 = hf * MT;
     const int r = lane & 15, q4 = lane >> 4;
     const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
@@ -282,7 +319,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
             rc[ps] = prm.c[(int64_t)bh * N + rcl];
         }
     };
-    for (int i = tid; i < (SP * SIMG) / 16; i += 256) *reinterpret_cast<f32x4*>(smem + R2I + 16 * i) = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < (SP * SIMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + R2I + 16 * i) = f32x4{0, 0, 0, 0};
     if (tid < DP) {
         reinterpret_cast<float*>(smem + R1)[tid] = 0.f;          // parity buffers are indexed by (chunk & 1)
         reinterpret_cast<float*>(smem + R1)[DP + tid] = 0.f;
@@ -304,8 +341,8 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
         for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                r2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (w + 4 * sl) + r) * DP + 16 * dt + 4 * q4);
-            publish_state<DP, SP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+                r2acc[sl][dt] = *reinterpret_cast<const f32x4*>(rec + (16 * (wk + 4 * sl) + r) * DP + 16 * (t0 + dt) + 4 * q4);
+            publish_state<DP, SP, DT>(smem, R2I, SIMG, r2acc[sl], a, 16 * (wk + 4 * sl) + r, q4, t0);
         }
         if (tid < DP) {
             const int par = (c_end - 1) & 1;
@@ -346,7 +383,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
         }
         if (c > c_begin) issue(n0 - C);
         __syncthreads();                                             // B1
-        for (int t = tid; t < 2 * DP; t += 256) {                    // suffix sums for the next (earlier) chunk
+        for (int t = tid; t < 2 * DP; t += NT) {                    // suffix sums for the next (earlier) chunk
             const int col = t % DP;
             const bool isg = t < DP;
             const float* part = reinterpret_cast<const float*>(smem + (isg ? PARTG : PARTQ));
@@ -357,7 +394,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
             base[DP * nxt + col] = base[DP * cur + col] + (isg ? s : a * s);
         }
         // ---- phase A: this wave's 16 keys j = 16w + r ---------------------------------------------------
-        const int kj = 16 * w + r;
+        const int kj = 16 * wk + r;
         Frag<NP> kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -370,16 +407,16 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             // dK^T[m][j] = rq'[m] + sum_d (a R2)[m][d] V[j][d]
-            dkacc[t] = *reinterpret_cast<const f32x4*>(rq_cur + 16 * t + 4 * q4);
+            dkacc[t] = *reinterpret_cast<const f32x4*>(rq_cur + 16 * (t0 + t) + 4 * q4);
             // dV^T[d][j] = R1[d] + sum_m (a R2)[m][d] K[j][m]
-            dvacc[t] = *reinterpret_cast<const f32x4*>(r1_cur + 16 * t + 4 * q4);
+            dvacc[t] = *reinterpret_cast<const f32x4*>(r1_cur + 16 * (t0 + t) + 4 * q4);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag<SP> rf, rtf;
 #pragma unroll
                 for (int p = 0; p < SP; ++p) {
-                    rf.p[p] = *reinterpret_cast<const bf16x8*>(smem + R2I + p * SIMG + img_off<DP>(16 * t + r, 4 * ks + q4));
-                    rtf.p[p] = ld_tr8<DP>(smem, R2I + p * SIMG, 32 * ks, 16 * t, lane);     // A[row d][k = m], permuted k
+                    rf.p[p] = *reinterpret_cast<const bf16x8*>(smem + R2I + p * SIMG + img_off<DP>(16 * (t0 + t) + r, 4 * ks + q4));
+                    rtf.p[p] = ld_tr8<DP>(smem, R2I + p * SIMG, 32 * ks, 16 * (t0 + t), lane);     // A[row d][k = m], permuted k
                 }
                 dkacc[t] = mfma_parts<SP, NP>(rf, vf[ks], dkacc[t]);
                 Frag<NP> kpf;
@@ -397,7 +434,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
                 const int it = 2 * s + e;                            // 16 queries of the chunk
                 f32x4 u = *reinterpret_cast<const f32x4*>(smem + ES + (16 * it + 4 * q4) * 4);    // e_i per register row
                 f32x4 sc = {0, 0, 0, 0};
-                if (it >= w) {
+                if (it >= wk) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         Frag<NP> gf, qf;
@@ -412,7 +449,7 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool keep = (it > w) || (it == w && (4 * q4 + i) >= r);
+                    const bool keep = (it > wk) || (it == wk && (4 * q4 + i) >= r);
                     // rows past N carry w_i = 0 -> ghat = 0, e = 0, and P is multiplied by ghat rows (zero) below
                     tt[e][i] = keep ? a * u[i] : 0.f;
                     pp[e][i] = keep ? 1.0f + a * sc[i] : 0.f;
@@ -426,14 +463,14 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (2 * s + 1 >= w) {
+            if (2 * s + 1 >= wk) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     Frag<NP> qtf, gtf;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        qtf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * t, lane);
-                        gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * t, lane);
+                        qtf.p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * (t0 + t), lane);
+                        gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * (t0 + t), lane);
                     }
                     dkacc[t] = mfma_parts<NP, 2>(qtf, tf[s], dkacc[t]);      // += Q[i][m] a T_ij
                     dvacc[t] = mfma_parts<NP, 2>(gtf, pf[s], dvacc[t]);      // += ghat[i][d] P_ij
@@ -447,24 +484,33 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) qf[sl].p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * (w + 4 * sl), lane);
+                for (int p = 0; p < NP; ++p) qf[sl].p[p] = ld_tr8<DP>(smem, QI + p * IMG, 32 * s, 16 * (wk + 4 * sl), lane);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 Frag<NP> gtf;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * dt, lane);
+                for (int p = 0; p < NP; ++p) gtf.p[p] = ld_tr8<DP>(smem, GI + p * IMG, 32 * s, 16 * (t0 + dt), lane);
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) r2acc[sl][dt] = mfma_parts<NP, NP>(gtf, qf[sl], r2acc[sl][dt]);
             }
         }
         __syncthreads();                                             // B2
-        store_tile16<DP>(smem + w * (16 * DP * 4), dkacc, 1.0f, lane, prm.dk, prm.grad_dtype,   // a is already folded in
-                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
-        store_tile16<DP>(smem + DP * 256 + w * (16 * DP * 4), dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
-                         ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        if constexpr (NW == 4) {
+            store_tile16<DP>(smem + w * (16 * DP * 4), dkacc, 1.0f, lane, prm.dk, prm.grad_dtype,   // a is already folded in
+                             ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+            store_tile16<DP>(smem + DP * 256 + w * (16 * DP * 4), dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
+                             ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
+        } else {
+            // the Q / K / V / G images are free after B2: 8 waves x 2 areas of 16 x (DP/2) x 4 bytes
+            constexpr int AREA = 16 * 16 * MT * 4;
+            store_cols16<16 * MT>(smem + (2 * w) * AREA, dkacc, 1.0f, lane, prm.dk, prm.grad_dtype,
+                                  ((int64_t)bh * N + n0 + 16 * wk) * D, 16 * t0, n0 + 16 * wk, N, D);
+            store_cols16<16 * DT>(smem + (2 * w + 1) * AREA, dvacc, 1.0f, lane, prm.dv, prm.grad_dtype,
+                                  ((int64_t)bh * N + n0 + 16 * wk) * D, 16 * t0, n0 + 16 * wk, N, D);
+        }
         if (c > c_begin) {
 #pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP>(smem, R2I, SIMG, r2acc[sl], a, 16 * (w + 4 * sl) + r, q4);
+            for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP, DT>(smem, R2I, SIMG, r2acc[sl], a, 16 * (wk + 4 * sl) + r, q4, t0);
         }
         __syncthreads();
     }
@@ -472,13 +518,18 @@ __global__ __launch_bounds__(256, (InTraits<TIN>::NP == 1 && DP == 64) ? 2 : 1) 
 
 template <int DP, typename TIN>
 static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
-    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
+    // (one workgroup per CU, column halves per wave) everywhere else
+    constexpr int NWQ = DP == 64 ? 4 : 8, NWKV = (DP == 64 && NP == 1) ? 4 : 8;
+    constexpr int RPPQ = 64 * NWQ / (DP / EPL), RPPKV = 64 * NWKV / (DP / EPL);
     constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
-    constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPP * DP * 4 + 512;
-    constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPP * DP * 4 + 256;
-    static_assert(lds_kv <= 160 * 1024, "LDS budget");
-    auto kq = bwd_p1_dq_kernel<DP, TIN>;
-    auto kkv = bwd_p1_dkv_kernel<DP, TIN>;
+    constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPPQ * DP * 4 + 512 + (NWQ == 8 ? 8 * 16 * (DP / 2) * 4 : 0);
+    constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256;
+    static_assert(lds_kv <= 160 * 1024 && lds_q <= 160 * 1024, "LDS budget");
+    static_assert(NWKV == 4 || 8 * 2 * 16 * (DP / 2) * 4 <= 4 * NP * IMG, "dK/dV staging areas fit the freed images");
+    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ>;
+    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
@@ -487,13 +538,13 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kq, dim3(BH * prm.nseg), dim3(256), lds_q, stream, prm);
+    hipLaunchKernelGGL(kq, dim3(BH * prm.nseg), dim3(64 * NWQ), lds_q, stream, prm);
     if (prm.nseg > 1) {
         const int rc = launch_split_rstates(prm.q, prm.qs, prm.go, prm.gos, prm.g, prm.c, const_cast<float*>(prm.rstate), prob,
                                             SplitPlan{prm.nseg, prm.cps}, DP, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(256), lds_kv, stream, prm);
+    hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
     return (int)hipGetLastError();
 }
 

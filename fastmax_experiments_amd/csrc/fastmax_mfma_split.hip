@@ -157,8 +157,10 @@ __global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int 
 }
 
 SplitPlan split_plan(const fastmax_problem& p) {
-    // aim at `target` workgroups (two per CU); FASTMAX_SPLIT_TARGET overrides for experiments
-    static const int target = [] { const char* e = getenv("FASTMAX_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    // aim at two workgroups per CU for D <= 64 and one for D > 64 (those kernels hold a 128 x 128 state: one 8-wave
+    // workgroup per CU); FASTMAX_SPLIT_TARGET overrides for experiments (measured: 512 is the optimum at D = 64)
+    static const int forced = [] { const char* e = getenv("FASTMAX_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
+    const int target = forced ? forced : (p.D > 64 ? 256 : 512);
     const int BH = p.B * p.H, nchunks = (p.Nq + 63) / 64;
     if (BH >= target * 3 / 4 || nchunks < 8) return SplitPlan{1, nchunks};
     int nseg = (target + BH - 1) / BH;

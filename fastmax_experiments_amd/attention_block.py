@@ -15,6 +15,7 @@ attention operator is stock tensor plumbing.
 import torch
 import torch.nn as nn
 
+from . import ops
 from .attention_mechanisms.fastmax import fastmax
 from .attention_mechanisms.fastmax_hack import fastmax_hack
 from .lora import LoRALinear, LoRAQKVLinear
@@ -47,6 +48,7 @@ class CausalSelfAttention(nn.Module):
         if attn_alg not in ("fastmax", "linearmax"):
             raise ValueError(f"Attention algorithm {attn_alg} not supported")          # model.py:450-451
         self.attn_alg = attn_alg
+        self.fused_neighbours = True          # False: the reference's tensor-op sequence (kept for parity tests)
         shape = (n_head + 2 * self.n_query_groups) * self.head_size
         self.attn = LoRAQKVLinear(n_embd, shape, n_head=n_head, n_query_groups=self.n_query_groups, r=r, lora_alpha=alpha,
                                   lora_dropout=dropout, enable_lora=(to_query, to_key, to_value), bias=bias)
@@ -64,18 +66,25 @@ class CausalSelfAttention(nn.Module):
         qkv = self.attn(x)
         q_per_kv = self.n_head // self.n_query_groups
         total_qkv = q_per_kv + 2
-        qkv = qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size).permute(0, 2, 3, 1, 4)
-        q, k, v = qkv.split((q_per_kv, 1, 1), dim=2)
-        if self.n_query_groups != self.n_head and (input_pos is None or self.n_query_groups != 1):
-            k = k.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
-            v = v.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
-        q = q.reshape(B, -1, T, self.head_size)
-        k = k.reshape(B, -1, T, self.head_size)
-        v = v.reshape(B, -1, T, self.head_size)
-        q_roped = apply_rope(q[..., :self.rope_n_elem], cos, sin)
-        k_roped = apply_rope(k[..., :self.rope_n_elem], cos, sin)
-        q = torch.cat((q_roped, q[..., self.rope_n_elem:]), dim=-1)
-        k = torch.cat((k_roped, k[..., self.rope_n_elem:]), dim=-1)
+        fused = (self.fused_neighbours and x.device.type == "cuda" and input_pos is None and
+                 ops.rope_qkv_supported(qkv.dtype, self.head_size, self.rope_n_elem))
+        if fused:
+            # de-interleave + RoPE + GQA expand in one HIP pass, same values as the tensor ops below
+            q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
+                                             self.rope_n_elem)
+        else:
+            qkv = qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size).permute(0, 2, 3, 1, 4)
+            q, k, v = qkv.split((q_per_kv, 1, 1), dim=2)
+            if self.n_query_groups != self.n_head and (input_pos is None or self.n_query_groups != 1):
+                k = k.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
+                v = v.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
+            q = q.reshape(B, -1, T, self.head_size)
+            k = k.reshape(B, -1, T, self.head_size)
+            v = v.reshape(B, -1, T, self.head_size)
+            q_roped = apply_rope(q[..., :self.rope_n_elem], cos, sin)
+            k_roped = apply_rope(k[..., :self.rope_n_elem], cos, sin)
+            q = torch.cat((q_roped, q[..., self.rope_n_elem:]), dim=-1)
+            k = torch.cat((k_roped, k[..., self.rope_n_elem:]), dim=-1)
         mask = input_pos is None                                   # model.py:462-466, 477-481
         if self.attn_alg == "linearmax":
             y = fastmax_hack(q, k, v, p=1, mask=mask)              # model.py:472

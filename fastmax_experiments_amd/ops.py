@@ -190,3 +190,44 @@ def linearmax_forward_fused(q, k, v):
 def effective_normalize_term(D, normalize_term, tensors_normalized):
     # attention_mechanisms/fastmax.py:78-82
     return 1.0 if tensors_normalized is True else normalize_term * math.sqrt(D)
+
+
+def rope_qkv_supported(dtype, head_size, rope_n_elem):
+    e = 4 if dtype == torch.float32 else 8
+    return dtype in _DT and rope_n_elem % 2 == 0 and (rope_n_elem // 2) % e == 0 and (head_size - rope_n_elem) % e == 0
+
+
+class RopeQKVSplit(torch.autograd.Function):
+    """qkv (B,T,G,q_per_kv+2,hs) -> q (B,H,T,hs), k, v (B,H,T,hs): de-interleave + RoPE + GQA expand in one HIP pass
+    (fastmax_rope.hip; lit_gpt/model.py:397-425), and the mirror pass for the gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, rope_n_elem):
+        L = _lib.lib()
+        B, T, G, total, hs = qkv.shape
+        qpk = total - 2
+        qkv = qkv.contiguous()
+        cos = cos[:T, :rope_n_elem].float().contiguous()
+        sin = sin[:T, :rope_n_elem].float().contiguous()
+        q, k, v = (torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device) for _ in range(3))
+        with torch.cuda.device(qkv.device):
+            rc = L.fastmax_hip_rope_qkv_split(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
+                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, 1, _DT[qkv.dtype], _stream(qkv.device))
+        _lib.check(rc, "fastmax_hip_rope_qkv_split")
+        ctx.save_for_backward(cos, sin)
+        ctx.dims = (B, T, G, qpk, hs, rope_n_elem)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        L = _lib.lib()
+        cos, sin = ctx.saved_tensors
+        B, T, G, qpk, hs, rope_n_elem = ctx.dims
+        gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
+        gqkv = torch.empty((B, T, G, qpk + 2, hs), dtype=gq.dtype, device=gq.device)
+        with torch.cuda.device(gq.device):
+            rc = L.fastmax_hip_rope_qkv_split_backward(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                       gqkv.data_ptr(), B, T, G, qpk, hs, rope_n_elem, 1, _DT[gq.dtype],
+                                                       _stream(gq.device))
+        _lib.check(rc, "fastmax_hip_rope_qkv_split_backward")
+        return gqkv, None, None, None

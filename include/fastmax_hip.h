@@ -137,6 +137,21 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
                                   void* workspace, size_t workspace_bytes, void* stream);
 /*      workspace of the fused call = fastmax_hip_forward_workspace(prob) (sequence-split states)   */
 
+/* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:
+ *      qkv (B, T, G, q_per_kv + 2, head_size), the QKV linear's output  ->  q (B, G*q_per_kv, T, head_size),
+ *      k, v (B, G*q_per_kv, T, head_size) when expand_kv != 0 (the reference's GQA expand) or (B, G, T, head_size);
+ *      RoPE (apply_rope, model.py:702-708) on the first rope_n_elem elements of q and k with cos, sin: (T, rope_n_elem) float32.
+ *      Replaces view/permute/split/expand/reshape copies + five elementwise launches + two cats per tensor.
+ *      rope_n_elem / 2 and head_size - rope_n_elem must be multiples of 16 bytes of elements (else FASTMAX_E_BAD_SHAPE).
+ *      _backward: gradients of q, k, v in the same layouts -> gradient of qkv (sum over the query heads of a group for k, v,
+ *      inverse rotation, re-interleave).                                                                               */
+int fastmax_hip_rope_qkv_split(const void* qkv, const float* cos, const float* sin, void* q, void* k, void* v,
+                               int B, int T, int G, int q_per_kv, int head_size, int rope_n_elem, int expand_kv,
+                               int dtype, void* stream);
+int fastmax_hip_rope_qkv_split_backward(const void* grad_q, const void* grad_k, const void* grad_v, const float* cos,
+                                        const float* sin, void* grad_qkv, int B, int T, int G, int q_per_kv,
+                                        int head_size, int rope_n_elem, int expand_kv, int dtype, void* stream);
+
 /* ---- decode-time state cache (opt-in): O(D^2) per generated token instead of the reference's
  *      unmasked recompute over the zero-padded KV cache (lit_gpt/model.py:427-430,464-466, generate/base.py:85-92).
  *      state: per (b,h) record [S2 (DPxDP) | S1 (DP) | ksum (DP)] float32, DP = 64 (D <= 64) or 128.

@@ -108,3 +108,62 @@ def test_dp_finetune_step_on_gpu():
     assert not torch.equal(before, blk.attn.lora_B.detach()) and torch.isfinite(l0)
     l1 = loss_fn(blk, (x[:2], tgt[:2]))
     assert torch.isfinite(l1)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 0.0), (torch.bfloat16, 0.0), (torch.float16, 0.0)])
+@pytest.mark.parametrize("B,T,G,qpk,hs,rot", [(2, 129, 4, 8, 64, 1.0), (1, 300, 2, 1, 128, 1.0), (2, 64, 3, 2, 64, 0.5), (1, 17, 1, 4, 32, 0.5)])
+def test_fused_neighbours_kernel_matches_the_tensor_ops(B, T, G, qpk, hs, rot, dt, tol):
+    """fastmax_rope.hip (de-interleave + RoPE + GQA expand, and its backward) against the tensor-op sequence of
+    lit_gpt/model.py:397-425: the forward reproduces the reference's roundings and is bit-identical"""
+    from fastmax_experiments_amd import ops
+    from fastmax_experiments_amd.attention_block import apply_rope, build_rope_cache
+    n = int(rot * hs)
+    if not ops.rope_qkv_supported(dt, hs, n):
+        pytest.skip("piece alignment")
+    g = torch.Generator().manual_seed(T + hs)
+    qkv = torch.randn(B, T, G, qpk + 2, hs, generator=g).to(dt).cuda()
+    gq, gk, gv = (torch.randn(B, G * qpk, T, hs, generator=g).to(dt).cuda() for _ in range(3))
+    cos, sin = build_rope_cache(T, n, device="cuda")
+
+    def tensor_ops(x):
+        y = x.permute(0, 2, 3, 1, 4)
+        q, k, v = y.split((qpk, 1, 1), dim=2)
+        k = k.expand(B, G, qpk, T, hs)
+        v = v.expand(B, G, qpk, T, hs)
+        q, k, v = (t.reshape(B, -1, T, hs) for t in (q, k, v))
+        q = torch.cat((apply_rope(q[..., :n], cos, sin), q[..., n:]), -1)
+        k = torch.cat((apply_rope(k[..., :n], cos, sin), k[..., n:]), -1)
+        return q, k, v
+
+    a = qkv.clone().requires_grad_(True)
+    b = qkv.clone().requires_grad_(True)
+    qa, ka, va = ops.RopeQKVSplit.apply(a, cos, sin, n)
+    qb, kb, vb = tensor_ops(b)
+    for x, y in ((qa, qb), (ka, kb), (va, vb)):
+        assert x.shape == y.shape and rel_err(x.detach().float().cpu().numpy(), y.detach().float().cpu().numpy()) <= tol
+    torch.autograd.backward((qa, ka, va), (gq, gk, gv))
+    torch.autograd.backward((qb, kb, vb), (gq, gk, gv))
+    # the tensor-op backward rounds the per-head k, v gradients before summing the group; the kernel sums in fp32
+    assert rel_err(a.grad.float().cpu().numpy(), b.grad.float().cpu().numpy()) < (1e-6 if dt == torch.float32 else 6e-3)
+
+
+def test_block_with_and_without_fused_neighbours():
+    from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache
+    torch.manual_seed(0)
+    cfg = CONFIG_SHAPES["tiny-llama-1.1b"]
+    blk = CausalSelfAttention(cfg["n_embd"], cfg["n_head"], n_query_groups=cfg["n_query_groups"], attn_alg="linearmax").to(torch.bfloat16)
+    torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
+    blk.quantize_base().cuda()
+    T = 512
+    cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    x = torch.randn(2, T, cfg["n_embd"], device="cuda", dtype=torch.bfloat16)
+    outs, grads = [], []
+    for fused in (True, False):
+        blk.fused_neighbours = fused
+        xx = x.clone().requires_grad_(True)
+        y = blk(xx, cos, sin)
+        y.backward(torch.ones_like(y))
+        outs.append(y.detach().float().cpu().numpy())
+        grads.append(xx.grad.float().cpu().numpy())
+    assert rel_err(outs[0], outs[1]) < 5e-3
+    assert rel_err(grads[0], grads[1]) < 1e-2

@@ -30,14 +30,43 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _compile_one(args):
+    cc, src, obj, extra, verbose = args
+    cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + extra + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return obj
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into fastmax_experiments_amd/libfastmax_hip.so."""
+    """Compile every HIP source for gfx950 into fastmax_experiments_amd/libfastmax_hip.so.
+    One object per source (compiled in parallel, only the stale ones), then one link."""
     if not force and not stale():
         return LIB
-    extra = os.environ.get("FASTMAX_HIPCC_EXTRA", "").split()      # e.g. -DFASTMAX_QUAD32_ABLATION for tools/ablate builds
-    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB] + SOURCES
+    from concurrent.futures import ThreadPoolExecutor
+    cc = _hipcc()
+    extra = os.environ.get("FASTMAX_HIPCC_EXTRA", "").split()      # e.g. -DFASTMAX_QUAD32_ABLATION for ablation builds
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    tag = os.path.join(objdir, ".flags")
+    flags_now = " ".join(extra)
+    flags_changed = not os.path.exists(tag) or open(tag).read() != flags_now
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        src_time = max(os.path.getmtime(os.path.join(CSRC, src)), hdr_time)
+        if force or flags_changed or not os.path.exists(obj) or os.path.getmtime(obj) < src_time:
+            jobs.append((cc, src, obj, extra, verbose))
+    workers = max(1, min(8, (os.cpu_count() or 2), len(jobs) or 1))
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(_compile_one, jobs))
+    open(tag, "w").write(flags_now)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
     return LIB
 

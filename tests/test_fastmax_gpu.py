@@ -569,3 +569,30 @@ def test_linearmax_prologue_backward_is_reproducible():
     _, inv = ops.normalize_cast(x)
     a, b = ops.normalize_backward(x, gy, inv), ops.normalize_backward(x, gy, inv)
     assert torch.equal(a, b)
+
+
+def test_forward_is_hip_graph_capturable():
+    """launch-bound shapes (C2: five launches for 0.03 ms of work): after one eager warm-up call (one-time function attributes)
+    the whole linearmax forward records into a HIP graph and replays with new inputs"""
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(16, 4, 1024, 32, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    with torch.no_grad():
+        ref = fastmax_hack(q, k, v, p=1, mask=True)                # warm-up + eager result
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fastmax_hack(q, k, v, p=1, mask=True)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fastmax_hack(q, k, v, p=1, mask=True)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        q2 = torch.randn(16, 4, 1024, 32, generator=g).to(torch.bfloat16).cuda()
+        ref2 = fastmax_hack(q2, k, v, p=1, mask=True)
+        q.copy_(q2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref2)

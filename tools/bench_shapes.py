@@ -44,6 +44,7 @@ def main():
         ("headline p=2 fwd+bwd bf16", "fastmax", (16, 32, 4096, 64), "bf16", 2, "fwd+bwd"),
         ("C2 pythia-14m heads fastmax(p=2)", "fastmax", (16, 4, 1024, 32), "bf16", 2, "fwd"),
         ("C2 pythia-14m heads linearmax", "linearmax", (16, 4, 1024, 32), "bf16", 1, "fwd"),
+        ("C2 linearmax, HIP graph replay", "linearmax_graph", (16, 4, 1024, 32), "bf16", 1, "fwd"),
         ("C3 tinyllama heads fastmax(p=2)", "fastmax", (8, 32, 2048, 64), "bf16", 2, "fwd"),
         ("C3 tinyllama heads fastmax(p=2) fwd+bwd", "fastmax", (8, 32, 2048, 64), "bf16", 2, "fwd+bwd"),
         ("C3 tinyllama heads linearmax", "linearmax", (8, 32, 2048, 64), "bf16", 1, "fwd"),
@@ -69,7 +70,23 @@ def main():
         if train:
             q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
 
+        graph = None
+        if op == "linearmax_graph":                      # launch-bound shape: record the five launches once, replay
+            with torch.no_grad():
+                fastmax_hack(q, k, v, p=p, mask=True)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fastmax_hack(q, k, v, p=p, mask=True)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    fastmax_hack(q, k, v, p=p, mask=True)
+
         def step():
+            if graph is not None:
+                graph.replay()
+                return
             with torch.set_grad_enabled(train):
                 o = fastmax_hack(q, k, v, p=p, mask=True) if op == "linearmax" else fastmax(q, k, v, mask=True, p=p)
                 if train:
@@ -77,7 +94,7 @@ def main():
                     o.backward(go)
 
         path = _lib.PATH_NAMES.get(ops.selected_path(q, k, p, True), "?")
-        if op == "linearmax":
+        if op.startswith("linearmax"):
             path = "mfma+fused prologue" if not train else path
         ms = timeit(step, 10 if ms_guess(shape, p) < 20 else 3)
         es = 4 if dt == "f32" else 2

@@ -57,8 +57,9 @@ template <int NPP> __device__ __forceinline__ void pack_tile(const float (&x)[16
 }
 
 // ---- dQ: one wave = 32 queries, NW waves per workgroup, loop over 64-key tiles ---------------------------------------------
-template <int DP, int P, typename TIN, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && (DP == 64 || InTraits<TIN>::NP == 1)) ? 2 : 1) void bwd32_dq_kernel(Quad32BwdParams prm) {
+// MB = minimum workgroups per CU the register allocation must allow (2 -> 256 registers at NW = 4; 1 -> the whole file)
+template <int DP, int P, typename TIN, int NW, int MB>
+__global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
     constexpr int NT = 64 * NW, QT = 32 * NW;
     constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG;          // K (dual use) then V (row reads)
@@ -369,32 +370,56 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
     store_tile32_t<DT>(smem + w * 4096, dvacc, 1.0f, lane, prm.dv, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
 }
 
-template <int DP, int P, typename TIN, int NW>
-static int launch_bwd32_w(Quad32BwdParams prm, hipStream_t stream) {
+template <int DP, int P, typename TIN, int NW, int MB>
+static int launch_bwd32_dq(Quad32BwdParams prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
-    constexpr int st_q = 2 * 2 * NP * img_bytes<DP, 3>(), st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 512), epi = NW * 4096;
-    constexpr int lds_q = st_q > epi ? st_q : epi, lds_kv = st_kv > epi ? st_kv : epi;
-    auto kq = bwd32_dq_kernel<DP, P, TIN, NW>;
-    auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW>;
+    constexpr int st_q = 2 * 2 * NP * img_bytes<DP, 3>(), epi = NW * 4096;
+    constexpr int lds_q = st_q > epi ? st_q : epi;
+    auto kq = bwd32_dq_kernel<DP, P, TIN, NW, MB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     prm.nblk = (prm.Nq + 32 * NW - 1) / (32 * NW);
     hipLaunchKernelGGL(kq, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_q, stream, prm);
+    return (int)hipGetLastError();
+}
+template <int DP, int P, typename TIN, int NW>
+static int launch_bwd32_dkv(Quad32BwdParams prm, hipStream_t stream) {
+    constexpr int NP = InTraits<TIN>::NP;
+    constexpr int st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 512), epi = NW * 4096;
+    constexpr int lds_kv = st_kv > epi ? st_kv : epi;
+    auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     prm.nblk = (prm.Nk + 32 * NW - 1) / (32 * NW);
     hipLaunchKernelGGL(kkv, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_kv, stream, prm);
     return (int)hipGetLastError();
 }
 template <int DP, int P, typename TIN>
 static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
-    static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_BWD_NW"); return e ? atoi(e) : 0; }();
-    const int nw = forced ? forced : ((DP == 64 && InTraits<TIN>::NP == 2) ? 8 : 4);
-    return nw == 8 ? launch_bwd32_w<DP, P, TIN, 8>(prm, stream) : launch_bwd32_w<DP, P, TIN, 4>(prm, stream);
+    constexpr int NP = InTraits<TIN>::NP;
+    static const int vq = [] { const char* e = getenv("FASTMAX_BWD32_DQ"); return e ? atoi(e) : -1; }();
+    static const int vkv = [] { const char* e = getenv("FASTMAX_BWD32_DKV_NW"); return e ? atoi(e) : 0; }();
+    int rc;
+    // dQ variants: 0 = 4 waves, two workgroups per CU (256 registers); 1 = 4 waves, one workgroup per CU (whole file);
+    // 2 = 8 waves, one workgroup per CU
+    // measured (C4, bf16 D = 128): 2.14 / 1.67 / 1.81 ms forward+backward for variants 0 / 1 / 2 -- the 256-register cap
+    // spills 276 bytes per lane into the tile loop; D = 64: 5.75 / 5.99 / 5.85
+    constexpr int DEF_Q = (DP == 64 && NP == 2) ? 2 : (DP == 64 ? 0 : 1);
+    const int q = vq >= 0 ? vq : DEF_Q;
+    if (q == 2) rc = launch_bwd32_dq<DP, P, TIN, 8, 1>(prm, stream);
+    else if (q == 1) rc = launch_bwd32_dq<DP, P, TIN, 4, 1>(prm, stream);
+    else rc = launch_bwd32_dq<DP, P, TIN, 4, 2>(prm, stream);
+    if (rc) return rc;
+    const int nwkv = vkv ? vkv : ((DP == 64 && NP == 2) ? 8 : 4);
+    return nwkv == 8 ? launch_bwd32_dkv<DP, P, TIN, 8>(prm, stream) : launch_bwd32_dkv<DP, P, TIN, 4>(prm, stream);
 }
 template <int P, typename TIN>
 static int launch_bwd32_d(const Quad32BwdParams& prm, hipStream_t stream) {

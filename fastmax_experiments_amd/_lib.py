@@ -21,7 +21,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_abi_version", "fastmax_hip_select_path", "fastmax_hip_error_string",
            "fastmax_hip_decode_state_bytes", "fastmax_hip_p1_prefill_state", "fastmax_hip_p1_decode_step",
            "fastmax_hip_normalize_stats", "fastmax_hip_normalize_cast", "fastmax_hip_normalize_backward_workspace",
-           "fastmax_hip_normalize_backward", "fastmax_hip_rope_qkv_split", "fastmax_hip_rope_qkv_split_backward",
+           "fastmax_hip_normalize_backward", "fastmax_hip_rope_qkv_split", "fastmax_hip_rope_qkv_split_backward", "fastmax_hip_cross_entropy_forward", "fastmax_hip_cross_entropy_backward",
            "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
 
 
@@ -73,6 +73,11 @@ def lib():
     L.fastmax_hip_rope_qkv_split.restype = ci
     L.fastmax_hip_rope_qkv_split_backward.argtypes = [vp, vp, vp, fp, fp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.fastmax_hip_rope_qkv_split_backward.restype = ci
+    i64 = ctypes.c_int64
+    L.fastmax_hip_cross_entropy_forward.argtypes = [vp, i64, vp, fp, fp, i64, ci, i64, ci, vp]
+    L.fastmax_hip_cross_entropy_forward.restype = ci
+    L.fastmax_hip_cross_entropy_backward.argtypes = [vp, i64, vp, fp, fp, ctypes.c_float, vp, i64, i64, ci, i64, ci, vp]
+    L.fastmax_hip_cross_entropy_backward.restype = ci
     L.fastmax_hip_linearmax_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, fp, fp, vp, fp, vp, sz, vp]
     L.fastmax_hip_linearmax_forward.restype = ci
     i64 = ctypes.c_int64

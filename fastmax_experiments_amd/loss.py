@@ -1,0 +1,140 @@
+"""Loss path of the fine-tune step, mirroring the reference's interface:
+
+* ``chunked_cross_entropy(logits, targets, chunk_size=128, ignore_index=-1)`` -- lit_gpt/utils.py:228-272 (accepts the list of
+  lm-head chunks that ``GPT.forward(..., lm_head_chunk_size=128)`` returns, lora.py:547-550, or one tensor); the row-wise
+  cross entropy runs in libfastmax_hip.so (fastmax_ce.hip): one read of the logits forward, one read + one write backward.
+* ``lm_head_cross_entropy(x, weight, targets)`` -- the chunked head and the loss together: logits exist one row-chunk at a
+  time (library GEMM -> HIP cross entropy), forward and backward; nothing of size (tokens x vocabulary) is kept.
+
+There is no CPU fallback: device tensors only.
+"""
+import ctypes
+from typing import List, Union
+
+import torch
+
+from . import _lib
+from .ops import _DT, _stream
+
+
+def _rows_forward(logits2d, targets1d, ignore_index):
+    M, V = logits2d.shape
+    loss = torch.empty(M, dtype=torch.float32, device=logits2d.device)
+    lse = torch.empty(M, dtype=torch.float32, device=logits2d.device)
+    with torch.cuda.device(logits2d.device):
+        rc = _lib.lib().fastmax_hip_cross_entropy_forward(logits2d.data_ptr(), logits2d.stride(0), targets1d.data_ptr(),
+                                                          loss.data_ptr(), lse.data_ptr(), M, V, ignore_index, _DT[logits2d.dtype],
+                                                          _stream(logits2d.device))
+    _lib.check(rc, "fastmax_hip_cross_entropy_forward")
+    return loss, lse
+
+
+def _rows_backward(logits2d, targets1d, lse, grad_loss, grad_scale, ignore_index, out):
+    M, V = logits2d.shape
+    with torch.cuda.device(logits2d.device):
+        rc = _lib.lib().fastmax_hip_cross_entropy_backward(logits2d.data_ptr(), logits2d.stride(0), targets1d.data_ptr(),
+                                                           lse.data_ptr(), None if grad_loss is None else grad_loss.data_ptr(),
+                                                           ctypes.c_float(grad_scale), out.data_ptr(), out.stride(0), M, V,
+                                                           ignore_index, _DT[logits2d.dtype], _stream(logits2d.device))
+    _lib.check(rc, "fastmax_hip_cross_entropy_backward")
+    return out
+
+
+def _prep(logits, targets):
+    if logits.device.type != "cuda":
+        raise RuntimeError("the cross-entropy kernel runs on an MI355X only; there is no CPU fallback")
+    logits2d = logits.reshape(-1, logits.size(-1))
+    if logits2d.dtype not in _DT:
+        logits2d = logits2d.float()
+    if logits2d.stride(1) != 1:
+        logits2d = logits2d.contiguous()
+    return logits2d, targets.reshape(-1).to(torch.int64).contiguous()
+
+
+class _CrossEntropyRows(torch.autograd.Function):
+    """torch.nn.functional.cross_entropy(logits, targets, ignore_index=..., reduction="none") for (M, V) logits."""
+
+    @staticmethod
+    def forward(ctx, logits2d, targets1d, ignore_index):
+        loss, lse = _rows_forward(logits2d, targets1d, ignore_index)
+        ctx.save_for_backward(logits2d, targets1d, lse)
+        ctx.ignore_index = ignore_index
+        return loss.to(logits2d.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        logits2d, targets1d, lse = ctx.saved_tensors
+        out = torch.empty_like(logits2d)
+        _rows_backward(logits2d, targets1d, lse, grad_loss.float().contiguous(), 1.0, ctx.ignore_index, out)
+        return out, None, None
+
+
+def cross_entropy_rows(logits, targets, ignore_index=-100):
+    logits2d, targets1d = _prep(logits, targets)
+    return _CrossEntropyRows.apply(logits2d, targets1d, ignore_index)
+
+
+def chunked_cross_entropy(logits: Union[torch.Tensor, List[torch.Tensor]], targets: torch.Tensor, chunk_size: int = 128,
+                          ignore_index: int = -1) -> torch.Tensor:
+    """lit_gpt/utils.py:228-272.  The reference chunks to bound autograd's memory spike; the kernel keeps no per-chunk
+    temporaries, so every branch reduces to: per-row losses, summed, over the count of non-ignored targets (the mean that
+    ``cross_entropy``'s default reduction takes when ``chunk_size == 0``)."""
+    if isinstance(logits, list):
+        parts = [cross_entropy_rows(chunk, t, ignore_index)
+                 for chunk, t in zip(logits, targets.split(logits[0].size(1), dim=1))]
+        rows = torch.cat(parts)
+    else:
+        rows = cross_entropy_rows(logits, targets, ignore_index)
+    non_masked_elems = (targets != ignore_index).sum()
+    return rows.sum() / non_masked_elems.clamp(min=1)
+
+
+class _LMHeadLoss(torch.autograd.Function):
+    """mean cross entropy of (x W^T) against targets without materialising the (tokens x vocabulary) logits."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, targets1d, ignore_index, chunk_rows):
+        M = x2d.shape[0]
+        lse = torch.empty(M, dtype=torch.float32, device=x2d.device)
+        total = torch.zeros((), dtype=torch.float32, device=x2d.device)
+        for r0 in range(0, M, chunk_rows):
+            logits = x2d[r0:r0 + chunk_rows] @ weight.t()                  # library GEMM; freed at the end of the iteration
+            loss, l = _rows_forward(logits, targets1d[r0:r0 + chunk_rows], ignore_index)
+            lse[r0:r0 + chunk_rows] = l
+            total += loss.sum()
+        n = (targets1d != ignore_index).sum().clamp(min=1)
+        ctx.save_for_backward(x2d, weight, targets1d, lse, n)
+        ctx.ignore_index, ctx.chunk_rows = ignore_index, chunk_rows
+        return (total / n).to(x2d.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x2d, weight, targets1d, lse, n = ctx.saved_tensors
+        M = x2d.shape[0]
+        scale = float(grad_out.float() / n)                                 # one host sync per backward (scalar loss)
+        dx = torch.empty_like(x2d) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(weight, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        for r0 in range(0, M, ctx.chunk_rows):
+            xs = x2d[r0:r0 + ctx.chunk_rows]
+            logits = xs @ weight.t()
+            _rows_backward(logits, targets1d[r0:r0 + ctx.chunk_rows], lse[r0:r0 + ctx.chunk_rows], None, scale, ctx.ignore_index,
+                           logits)                                           # in place: logits become d(logits)
+            if dx is not None:
+                dx[r0:r0 + ctx.chunk_rows] = logits @ weight
+            if dw is not None:
+                dw.addmm_(logits.t().float(), xs.float())
+        return dx, None if dw is None else dw.to(weight.dtype), None, None, None
+
+
+def lm_head_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: torch.Tensor, ignore_index: int = -1,
+                          chunk_rows: int = 4096) -> torch.Tensor:
+    """mean over non-ignored targets of cross_entropy(x @ weight.T, targets): the reference's
+    ``model(input_ids, lm_head_chunk_size=128)`` + ``chunked_cross_entropy`` pair (finetune/lora.py:216-219) for a bias-free
+    head, with logits alive one ``chunk_rows`` block at a time in both directions."""
+    if x.device.type != "cuda":
+        raise RuntimeError("lm_head_cross_entropy runs on an MI355X only; there is no CPU fallback")
+    x2d = x.reshape(-1, x.size(-1))
+    if x2d.dtype not in _DT:
+        x2d = x2d.float()
+    return _LMHeadLoss.apply(x2d.contiguous(), weight.to(x2d.dtype), targets.reshape(-1).to(torch.int64).contiguous(), ignore_index,
+                             chunk_rows)

@@ -152,6 +152,18 @@ int fastmax_hip_rope_qkv_split_backward(const void* grad_q, const void* grad_k, 
                                         const float* sin, void* grad_qkv, int B, int T, int G, int q_per_kv,
                                         int head_size, int rope_n_elem, int expand_kv, int dtype, void* stream);
 
+/* ---- loss path of the fine-tune step: the row-wise cross entropy behind chunked_cross_entropy
+ *      (lit_gpt/utils.py:228-272; torch cross_entropy, reduction "none", ignore_index).
+ *      logits: (M, V) in `dtype` with row stride ld (elements); targets: (M) int64.
+ *      forward : lse[i] = log sum_v exp(z_iv);  loss[i] = lse[i] - z[i, t_i]   (0 where t_i == ignore_index)
+ *      backward: grad_logits[i, v] = (softmax(z_i)[v] - [v == t_i]) * grad_loss[i] * grad_scale   (grad_loss may be NULL = 1;
+ *                rows with an ignored target get 0); grad_logits may alias logits (in place).               */
+int fastmax_hip_cross_entropy_forward(const void* logits, int64_t ld, const int64_t* targets, float* loss, float* lse,
+                                      int64_t M, int V, int64_t ignore_index, int dtype, void* stream);
+int fastmax_hip_cross_entropy_backward(const void* logits, int64_t ld, const int64_t* targets, const float* lse,
+                                       const float* grad_loss, float grad_scale, void* grad_logits, int64_t ldg,
+                                       int64_t M, int V, int64_t ignore_index, int dtype, void* stream);
+
 /* ---- decode-time state cache (opt-in): O(D^2) per generated token instead of the reference's
  *      unmasked recompute over the zero-padded KV cache (lit_gpt/model.py:427-430,464-466, generate/base.py:85-92).
  *      state: per (b,h) record [S2 (DPxDP) | S1 (DP) | ksum (DP)] float32, DP = 64 (D <= 64) or 128.

@@ -567,12 +567,23 @@ static void launch_max_lpr(const void* x, Strides3 xs, int B, int H, int N, int 
     else hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
 }
 
+// zero the per-head max words with a kernel, not hipMemsetAsync: a memset node inside a captured HIP graph was observed
+// to run unordered with the kernel that follows it (a quarter of the words zeroed after the atomics; ROCm 7.2)
+__global__ void zero_words_kernel(unsigned int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static int zero_words(unsigned int* p, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n);
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 static int launch_normalize_t(const void* x, Strides3 xs, float* y, float* inv_norm, int B, int H, int N, int D,
                               void* ws, hipStream_t stream) {
     unsigned int* maxbits = reinterpret_cast<unsigned int*>(ws);
-    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
-    if (e != hipSuccess) return (int)e;
+    const int e = zero_words(maxbits, B * H, stream);
+    if (e) return e;
     dim3 grid((N + 3) / 4, B * H), block(256);
     launch_max_lpr<T>(x, xs, B, H, N, D, maxbits, stream);
     hipLaunchKernelGGL((normalize_apply_kernel<T>), grid, block, 0, stream, x, xs, H, N, D, maxbits, y, inv_norm);
@@ -586,8 +597,8 @@ template <typename T>
 static int launch_stats_t(const void* x, Strides3 xs, float* inv_norm, int B, int H, int N, int D, void* ws,
                           hipStream_t stream) {
     unsigned int* maxbits = reinterpret_cast<unsigned int*>(ws);
-    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * (size_t)B * H, stream);
-    if (e != hipSuccess) return (int)e;
+    const int e = zero_words(maxbits, B * H, stream);
+    if (e) return e;
     launch_max_lpr<T>(x, xs, B, H, N, D, maxbits, stream);
     hipLaunchKernelGGL(normalize_finish_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, maxbits, inv_norm, B * H);
     return (int)hipGetLastError();

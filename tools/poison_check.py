@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Uninitialised-read hunt: fill the caching allocator's free blocks with NaN bit patterns, then run the operators and look
+for NaN / differences against a run on zero-filled memory.  Any kernel that reads workspace or output memory before writing
+it shows up here."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from attention_mechanisms.fastmax import fastmax
+from attention_mechanisms.fastmax_hack import fastmax_hack
+
+
+def poison(value):
+    torch.cuda.synchronize()
+    blocks = []
+    try:
+        for _ in range(24):
+            blocks.append(torch.full((256 << 20,), value, dtype=torch.uint8, device="cuda"))     # 6 GiB
+    except RuntimeError:
+        pass
+    del blocks
+    torch.cuda.synchronize()
+
+
+def run(case):
+    op, B, H, N, D, dt, p, mask, train = case
+    g = torch.Generator().manual_seed(N + D)
+    q, k, v, go = (torch.randn(B, H, N, D, generator=g).to(dt).cuda() for _ in range(4))
+    f = fastmax_hack if op == "linearmax" else fastmax
+    if train:
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+        o = f(q, k, v, p=p, mask=mask)
+        o.backward(go.to(o.dtype))
+        return [o.detach().float().cpu(), q.grad.float().cpu(), k.grad.float().cpu(), v.grad.float().cpu()]
+    with torch.no_grad():
+        return [f(q, k, v, p=p, mask=mask).float().cpu()]
+
+
+cases = []
+for dt in (torch.bfloat16, torch.float32):
+    for op, p in (("linearmax", 1), ("fastmax", 1), ("fastmax", 2)):
+        for shape in ((16, 4, 1024, 32), (1, 32, 4096, 64), (2, 3, 777, 64), (1, 2, 1100, 128), (8, 32, 512, 64)):
+            for train in (False, True):
+                cases.append((op, *shape, dt, p, True, train))
+cases.append(("fastmax", 1, 4, 600, 64, torch.bfloat16, 2, False, True))
+bad = 0
+for case in cases:
+    poison(0)
+    a = run(case)
+    poison(0xFF)          # 0xFFFF.. = NaN in bf16 / fp32
+    b = run(case)
+    ok = all(torch.isfinite(y).all() and torch.equal(x, y) for x, y in zip(a, b))
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, [bool(torch.isfinite(y).all()) for y in b], flush=True)
+print(f"{len(cases)} cases, {bad} bad", flush=True)

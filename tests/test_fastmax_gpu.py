@@ -596,3 +596,33 @@ def test_forward_is_hip_graph_capturable():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref2)
+
+
+def test_results_do_not_depend_on_stale_device_memory():
+    """uninitialised-read hunt (tools/poison_check.py runs the full list): the allocator's free blocks are filled with
+    zeros, then with NaN bit patterns, and the operators must return identical, finite results both times"""
+    from attention_mechanisms.fastmax import fastmax
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+
+    def poison(value):
+        torch.cuda.synchronize()
+        blocks = [torch.full((256 << 20,), value, dtype=torch.uint8, device="cuda") for _ in range(8)]
+        del blocks
+        torch.cuda.synchronize()
+
+    def run(f, shape, dt, p):
+        g = torch.Generator().manual_seed(shape[2])
+        q, k, v, go = (torch.randn(shape, generator=g).to(dt).cuda() for _ in range(4))
+        q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+        o = f(q, k, v, p=p, mask=True)
+        o.backward(go)
+        return [t.float().cpu() for t in (o.detach(), q.grad, k.grad, v.grad)]
+
+    for f, shape, dt, p in ((fastmax_hack, (16, 4, 1024, 32), torch.bfloat16, 1), (fastmax, (1, 32, 2048, 64), torch.float32, 1),
+                            (fastmax, (2, 3, 777, 64), torch.bfloat16, 2), (fastmax_hack, (1, 2, 1100, 128), torch.bfloat16, 1)):
+        poison(0)
+        a = run(f, shape, dt, p)
+        poison(0xFF)
+        b = run(f, shape, dt, p)
+        for x, y in zip(a, b):
+            assert torch.isfinite(y).all() and torch.equal(x, y), (f.__name__, shape, dt, p)

@@ -114,8 +114,16 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or os.environ.get("FASTMAX_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise RCCL init with one rank
+    if multi:
+        # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a five-line banner on STDOUT at communicator creation;
+        # stdout carries exactly one JSON line here
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -150,7 +158,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -160,11 +168,11 @@ def main():
         step()
         ev[i + 1].record()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,7 +211,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

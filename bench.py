@@ -97,6 +97,12 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line (rank 0).  Libraries write there too -- the image exports NCCL_DEBUG=VERSION and RCCL
+    # prints a five-line banner (and its warnings) on stdout, NCCL_DEBUG_FILE notwithstanding -- so file descriptor 1 points
+    # at stderr for the whole run and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -116,10 +122,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or os.environ.get("FASTMAX_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise RCCL init with one rank
     if multi:
-        # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a five-line banner on STDOUT at communicator creation;
-        # stdout carries exactly one JSON line here
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -210,7 +212,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi:
         dist.destroy_process_group()
 

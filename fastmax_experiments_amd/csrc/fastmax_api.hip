@@ -31,7 +31,11 @@ int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
     const bool lin_mfma = lin && (mfma_p1_supported(p) || mfma_gen_supported(p, false));
     if (p.path == FASTMAX_PATH_MFMA) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
-    if (lin) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_PATH_RECURRENT;
+    if (lin && lin_mfma) return FASTMAX_PATH_MFMA;
+    // p = 1 masked shapes the linear-time matrix-core kernels do not cover (two-part operands at D > 64: their images and
+    // the D x D state do not fit 160 KB of LDS): the matrix-core tiles beat the vector-ALU recurrence up to N ~ 20 k
+    // (measured at D = 128: 2.5 vs 8.5 ms at N = 4096, 27 vs 34 ms at N = 16384)
+    if (lin) return (quad_mfma_supported(p) && p.Nq <= 20000) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_PATH_RECURRENT;
     return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_PATH_QUADRATIC;
 }
 bool aligned16(const void* ptr, const int64_t* s, int dtype) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 1
+#define FASTMAX_ABI_VERSION 2   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 

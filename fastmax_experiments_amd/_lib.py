@@ -98,7 +98,7 @@ def lib():
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 1:
+    if L.fastmax_hip_abi_version() != 2:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -29,7 +29,7 @@ int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_QUADRATIC_MFMA) return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_E_BAD_SHAPE;
     const bool lin = (p.p == 1 && p.causal);
     if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
-    const bool lin_mfma = lin && (mfma_p1_supported(p) || mfma_gen_supported(p, false));
+    const bool lin_mfma = lin && (mfma_p1_supported(p) || mfma_gen_supported(p, false) || mfma_d128_2p_supported(p));
     if (p.path == FASTMAX_PATH_MFMA) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
     if (lin && lin_mfma) return FASTMAX_PATH_MFMA;
     // p = 1 masked shapes the linear-time matrix-core kernels do not cover (two-part operands at D > 64: their images and
@@ -98,6 +98,7 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
     switch (path) {
         case FASTMAX_PATH_MFMA:
             if (mfma_p1_supported(*prob)) return launch_fwd_mfma_p1(a);
+            if (mfma_d128_2p_supported(*prob)) return launch_fwd_mfma_d128_2p(a, nullptr, nullptr);
             return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, nullptr, nullptr) : launch_fwd_mfma_gen(a, nullptr, nullptr);
         case FASTMAX_PATH_RECURRENT: return launch_fwd_recurrent_p1(a);
         case FASTMAX_PATH_QUADRATIC_MFMA: return quad32_supported(a.prob) ? launch_fwd_quad32(a) : launch_fwd_quad_mfma(a);
@@ -188,12 +189,13 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
     int rc = validate(prob);
     if (rc) return rc;
     if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides || !q_inv_norm || !k_inv_norm) return FASTMAX_E_NULL;
-    if (!mfma_gen_supported(*prob, true)) return FASTMAX_E_BAD_SHAPE;
+    if (!mfma_gen_supported(*prob, true) && !mfma_d128_2p_supported(*prob)) return FASTMAX_E_BAD_SHAPE;
     if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
           aligned16(v, v_strides, prob->in_dtype)) || (reinterpret_cast<uintptr_t>(o) & 15))
         return FASTMAX_E_ALIGNMENT;
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
+    if (mfma_d128_2p_supported(*prob)) return launch_fwd_mfma_d128_2p(a, q_inv_norm, k_inv_norm);
     return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, q_inv_norm, k_inv_norm) : launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }
 

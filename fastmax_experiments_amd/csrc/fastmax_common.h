@@ -117,6 +117,8 @@ struct SplitPlan { int nseg, cps; };
 SplitPlan split_plan(const fastmax_problem& p);
 size_t split_workspace_bytes(const fastmax_problem& p, int dp);
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
+int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);
+bool mfma_d128_2p_supported(const fastmax_problem& p);
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
                          const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream);
 size_t lin_bwd_workspace(const fastmax_problem& p);

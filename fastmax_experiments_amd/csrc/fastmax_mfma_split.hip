@@ -197,8 +197,7 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
 template <typename TIN, bool NORM>
 static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream) {
     if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream);
-    if constexpr (InTraits<TIN>::NP == 2) return FASTMAX_E_BAD_SHAPE;
-    else return launch_state_t<128, TIN, NORM>(prm, BH, stream);
+    return launch_state_t<128, TIN, NORM>(prm, BH, stream);
 }
 
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role

@@ -267,9 +267,8 @@ def test_linear_time_matrix_core_kernel_dtypes_and_head_sizes(shape, dt, tol):
     g = torch.Generator().manual_seed(shape[2] + shape[3])
     q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
     qq, kk, vv = q.cuda(), k.cuda(), v.cuda()
-    # two-part operands at D > 64 have no linear-time matrix-core kernel: the dispatcher takes the tiles (faster than the
-    # vector-ALU recurrence up to N ~ 20 k)
-    want = _lib.PATH_MFMA if (shape[3] <= 64 or dt == torch.bfloat16) else _lib.PATH_QUADRATIC_MFMA
+    # D <= 64: generic / bf16 kernels; 64 < D <= 128: the eight-wave kernels (bf16, and fp32 / fp16 with two-part operands)
+    want = _lib.PATH_MFMA
     assert ops.selected_path(qq, kk, 1, True) == want
     o = fastmax(qq, kk, vv)
     assert o.dtype == dt
@@ -305,8 +304,6 @@ def test_sequence_split_for_few_heads(shape, dt, tol):
     from attention_mechanisms.fastmax import fastmax
     from attention_mechanisms.fastmax_hack import fastmax_hack
     from oracle import c_oracle, fastmax_oracle as orc
-    if shape[3] == 128 and dt == torch.float32:
-        pytest.skip("fp32 D=128 runs on the vector-ALU recurrent kernel")
     g = torch.Generator().manual_seed(shape[2])
     q, k, v = (torch.randn(shape, generator=g).to(dt) for _ in range(3))
     o = fastmax(q.cuda(), k.cuda(), v.cuda())

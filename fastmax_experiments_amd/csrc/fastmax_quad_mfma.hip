@@ -252,7 +252,10 @@ static int launch_quad_p(const QuadMfmaParams& prm, int B, int p, hipStream_t st
 
 bool quad_mfma_supported(const fastmax_problem& p) {
     const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
-    return (p.D % epl) == 0 && p.D <= 128 && p.Nq >= 16;
+    // a handful of queries against a short key range stays on the vector-ALU tiles; a single new token against a long KV
+    // cache (generation, lit_gpt/model.py:464-466) must not: that kernel walks the keys with one query per wave
+    // (measured 4.6 ms at N_k = 4096, 46 ms at 16 k; the matrix-core tile with 15 idle query rows takes 0.07 ms)
+    return (p.D % epl) == 0 && p.D <= 128 && (p.Nq >= 16 || p.Nk >= 256);
 }
 
 int launch_fwd_quad_mfma(const FwdArgs& a) {

@@ -109,12 +109,20 @@ def test_decode_shapes_matrix_core_tiles():
     from attention_mechanisms.fastmax import fastmax
     from oracle import fastmax_oracle as orc
     g = torch.Generator().manual_seed(9)
-    for nq, nk in ((16, 100), (64, 64), (100, 333)):
+    # (1, 1000), (3, 300), (15, 4096): a few new tokens against a long cache -- matrix-core tiles with idle query rows
+    for nq, nk in ((16, 100), (64, 64), (100, 333), (1, 1000), (3, 300), (15, 4096), (1, 40)):
         q, k, v = torch.randn(2, 2, nq, 64, generator=g), torch.randn(2, 2, nk, 64, generator=g), torch.randn(2, 2, nk, 64, generator=g)
         for p in (1, 2):
             o = fastmax(q.cuda(), k.cuda(), v.cuda(), mask=False, p=p)
             ro, _ = orc.fastmax_fwd_dense(q.numpy(), k.numpy(), v.numpy(), mask=False, p=p)
-            assert rel_err(o.cpu().numpy(), ro) < TOL_FWD
+            # unmasked g carries the constant N_q (fastmax.py:271): with one or three queries g = N_q + a q.ksum can be close
+            # to zero and the quotient is ill-conditioned, whatever computes it
+            assert rel_err(o.cpu().numpy(), ro) < (TOL_FWD if nq >= 16 else 2e-3)
+    for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 2e-3)):          # 16-bit single-token decode, D = 128
+        q, k, v = (torch.randn(1, 4, n, 128, generator=g).to(dt) for n in (1, 2000, 2000))
+        o = fastmax(q.cuda(), k.cuda(), v.cuda(), mask=False, p=2)
+        ro, _ = orc.fastmax_fwd_dense(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=False, p=2)
+        assert rel_err(o.float().cpu().numpy(), ro) < tol
 
 
 def test_c1_baseline_config():

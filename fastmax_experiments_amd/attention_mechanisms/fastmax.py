@@ -72,11 +72,19 @@ class fastattention_einops(torch.autograd.Function):
             ctx.mark_non_differentiable(o, a)
             return o.to(home), a.to(home)
 
+        # head sizes that are not a whole number of 16-byte pieces would fall onto the vector-ALU kernels (measured 25-70x
+        # slower at N = 2048): zero columns change neither q.k nor the populated columns of f(q.k) v, so pad to a multiple of 8
+        # (nt keeps the true D) and slice the result
+        Dp = D if D % 8 == 0 else min(128, (D + 7) // 8 * 8)
+        if Dp != D:
+            qd, kd, vd = (torch.nn.functional.pad(t, (0, Dp - D)) for t in (qd, kd, vd))
         out_dt = _out_dtype(kdt, causal)
         o, g = ops.forward(qd, kd, vd, p, causal, nt, g0=float(q.shape[2]), out_dtype=out_dt)
         ctx.save_for_backward(qd, kd, vd, o, g)
         ctx.mask, ctx.normalize_term, ctx.p = mask, nt, p
-        ctx.home, ctx.in_dtype, ctx.forward_only = home, in_dtype, False
+        ctx.home, ctx.in_dtype, ctx.forward_only, ctx.D = home, in_dtype, False, D
+        if Dp != D:
+            o = o[..., :D].contiguous()
         if in_dtype == torch.float64:
             o = o.double()
         return o.to(home)
@@ -88,6 +96,8 @@ class fastattention_einops(torch.autograd.Function):
         q, k, v, o, g = ctx.saved_tensors
         causal = ctx.mask is not False
         go = o_grad.to(q.device)
+        if q.shape[-1] != ctx.D:                                  # padded head size: zero gradient columns in, slice out
+            go = torch.nn.functional.pad(go, (0, q.shape[-1] - ctx.D))
         if o.dtype != q.dtype:
             # unmasked bf16/fp16 (Q1): o and its gradient are float32 -> differentiate in float32
             q32, k32, v32 = (ops._prep(t.float(), q.device) for t in (q, k, v))
@@ -96,6 +106,8 @@ class fastattention_einops(torch.autograd.Function):
         else:
             dq, dk, dv = ops.backward(q, k, v, o, g, ops._prep(go.to(q.dtype), q.device), ctx.p, causal,
                                       ctx.normalize_term)
+        if q.shape[-1] != ctx.D:
+            dq, dk, dv = (t[..., :ctx.D].contiguous() for t in (dq, dk, dv))
         dq, dk, dv = (t.to(device=ctx.home, dtype=ctx.in_dtype) for t in (dq, dk, dv))
         return dq, dk, dv, None, None, None, None, None, None
 

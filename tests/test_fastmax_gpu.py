@@ -633,3 +633,26 @@ def test_results_do_not_depend_on_stale_device_memory():
         b = run(f, shape, dt, p)
         for x, y in zip(a, b):
             assert torch.isfinite(y).all() and torch.equal(x, y), (f.__name__, shape, dt, p)
+
+
+@pytest.mark.parametrize("dt,tf,tb", [(torch.float32, TOL_FWD, TOL_BWD), (torch.bfloat16, 8e-3, 2.5e-2)])
+@pytest.mark.parametrize("shape,p,mask", [((2, 3, 300, 50), 1, True), ((1, 2, 700, 33), 2, True), ((1, 4, 128, 5), 1, False),
+                                          ((1, 2, 600, 100), 2, False), ((1, 2, 1030, 127), 1, True)])
+def test_head_sizes_that_are_not_a_multiple_of_eight(shape, p, mask, dt, tf, tb):
+    """zero-padded to the next multiple of 8 inside the autograd function (nt keeps the true D): matrix-core kernels
+    instead of the vector-ALU fallbacks, same function"""
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    q, k, v, go = (torch.randn(shape, generator=g).to(dt) for _ in range(4))
+    qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o = fastmax(qq, kk, vv, mask=mask, p=p)
+    assert o.shape == tuple(shape)
+    ro, _ = c_oracle.fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=mask, p=p)
+    assert rel_err(o.detach().float().cpu().numpy(), ro) < max(tf, TOL_FWD)
+    o.backward(go.cuda().to(o.dtype))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=mask, p=p)
+    for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+        assert t.grad.shape == tuple(shape) and t.grad.dtype == dt
+        assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, n

@@ -164,7 +164,7 @@ int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtyp
     if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
     if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
-    if ((D * es) % 16 != 0 || D * es > 512) return FASTMAX_E_BAD_SHAPE;
+    if (D * es > 512) return FASTMAX_E_BAD_SHAPE;
     int rc = launch_normalize_stats(x, st(x_strides), dtype, inv_norm, B, H, N, D, workspace, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     return launch_normalize_cast(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, reinterpret_cast<hipStream_t>(stream));

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_reduce_kernel(const void* x
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         float v[EPL], gv[EPL];
         load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
-        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) s += v[e];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_apply_kernel(const void* x,
     const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         float gv[EPL];
-        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) gv[e] *= inv;
         if (n == nstar) {                                          // uniform per row group
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void normalize_bwd_apply_kernel(const void* x,
         const float gm = group_sum<LPR>(s) * invD;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) gv[e] -= gm;
-        store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, 1, gv);
+        store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
     }
 }
 
@@ -188,8 +188,9 @@ static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
 template <typename T>
 static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
-    if (need > 32 || D % epl != 0 || (reinterpret_cast<uintptr_t>(y) & 15)) return FASTMAX_E_BAD_SHAPE;
-    const int vec = nrm_vec_ok(x, xs, sizeof(T), D);
+    if (need > 32) return FASTMAX_E_BAD_SHAPE;
+    // 16-byte accesses need whole pieces per row and aligned rows on both sides; otherwise element-wise loads / stores
+    const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(y) & 15);
     const dim3 grid((N + 255) / 256, B * H), block(256);
 #define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec)
     NRM_LPR_SWITCH(need, CALL)
@@ -214,8 +215,8 @@ template <typename T>
 static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const float* inv_norm, void* gx, int B, int H, int N, int D,
                            void* ws, hipStream_t stream) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
-    if (need > 32 || D % epl != 0 || ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15)) return FASTMAX_E_BAD_SHAPE;
-    const int vec = nrm_vec_ok(x, xs, sizeof(T), D);
+    if (need > 32) return FASTMAX_E_BAD_SHAPE;
+    const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15);
     const int nblk = (N + 255) / 256;
     // 8-byte records first (alignment), then the floats
     unsigned long long* part_best = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);

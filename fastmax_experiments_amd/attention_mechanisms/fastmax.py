@@ -32,9 +32,19 @@ from .. import ops
 _KERNEL_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
 
+MAX_HEADS_PER_LAUNCH = 65535
+
+
 def fastmax(q, k, v, mask=True, normalize_term=8, tensors_normalized=False, p=1, dropout_rate=0.0,
             create_attn=False):
     """Wrapper around ``fastattention_einops`` (reference: fastmax.py:7-27)."""
+    B, H = q.shape[0], q.shape[1]
+    if B * H > MAX_HEADS_PER_LAUNCH and B > 1 and create_attn is False:
+        # (b,h) pairs ride on a 16-bit grid dimension in some kernels: run the batch in slices (heads are independent)
+        step = max(1, MAX_HEADS_PER_LAUNCH // H)
+        return torch.cat([fastattention_einops.apply(q[i:i + step], k[i:i + step], v[i:i + step], mask, normalize_term,
+                                                     tensors_normalized, p, dropout_rate, create_attn)
+                          for i in range(0, B, step)], dim=0)
     return fastattention_einops.apply(q, k, v, mask, normalize_term, tensors_normalized, p, dropout_rate,
                                       create_attn)
 

@@ -10,7 +10,7 @@ The prologue and the attention both run in libfastmax_hip.so; gradients flow thr
 import torch
 
 from .. import ops
-from .fastmax import _KERNEL_DTYPES, fastattention_einops
+from .fastmax import MAX_HEADS_PER_LAUNCH, _KERNEL_DTYPES, fastattention_einops
 
 
 class _NormalizeQK(torch.autograd.Function):
@@ -51,6 +51,10 @@ class _NormalizeQK(torch.autograd.Function):
 
 def fastmax_hack(q, k, v, p=1, mask=True):
     """linearmax (reference: fastmax_hack.py:5)."""
+    if q.shape[0] * q.shape[1] > MAX_HEADS_PER_LAUNCH and q.shape[0] > 1:
+        step = max(1, MAX_HEADS_PER_LAUNCH // q.shape[1])          # heads are independent: run the batch in slices
+        return torch.cat([fastmax_hack(q[i:i + step], k[i:i + step], v[i:i + step], p=p, mask=mask)
+                          for i in range(0, q.shape[0], step)], dim=0)
     dev = ops._device() if q.device.type != "cuda" else q.device
     home, in_dtype = q.device, q.dtype
     kdt = in_dtype if in_dtype in _KERNEL_DTYPES else torch.float32

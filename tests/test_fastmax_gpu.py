@@ -656,3 +656,14 @@ def test_head_sizes_that_are_not_a_multiple_of_eight(shape, p, mask, dt, tf, tb)
     for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
         assert t.grad.shape == tuple(shape) and t.grad.dtype == dt
         assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, n
+
+
+def test_more_than_65535_heads_run_in_batch_slices():
+    from attention_mechanisms.fastmax import fastmax
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn(70000, 1, 16, 16, generator=g).cuda() for _ in range(3))
+    o = fastmax(q, k, v, p=2)
+    ref = torch.cat([fastmax(q[i:i + 30000], k[i:i + 30000], v[i:i + 30000], p=2) for i in range(0, 70000, 30000)])
+    assert o.shape == q.shape and torch.equal(o, ref)
+    assert fastmax_hack(q, k, v, p=1).shape == q.shape

@@ -59,6 +59,11 @@ int main() {
     run("3 reads + 1 write, grid-stride, default policy", 4.0 * bytes, [&] { hipLaunchKernelGGL(mix3<0>, dim3(8192), dim3(256), 0, 0, a, b, c, o, n); });
     run("3 reads + 1 write, 512 WGs x 64 chunks, nt", 4.0 * bytes, [&] { hipLaunchKernelGGL(heads3<1>, dim3(512), dim3(256), 0, 0, a, b, c, o, 64); });
     run("3 reads + 1 write, 512 WGs x 64 chunks, default", 4.0 * bytes, [&] { hipLaunchKernelGGL(heads3<0>, dim3(512), dim3(256), 0, 0, a, b, c, o, 64); });
+    for (int wgs : {256, 1024, 2048, 4096}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "3 reads + 1 write, %d WGs x %d chunks, nt", wgs, 32768 / wgs);
+        run(nm, 4.0 * bytes, [&] { hipLaunchKernelGGL(heads3<1>, dim3(wgs), dim3(256), 0, 0, a, b, c, o, 32768 / wgs); });
+    }
     run("copy 1 read + 1 write, nt", 2.0 * bytes, [&] { hipLaunchKernelGGL(copy1<1>, dim3(8192), dim3(256), 0, 0, a, o, n); });
     run("copy 1 read + 1 write, default policy", 2.0 * bytes, [&] { hipLaunchKernelGGL(copy1<0>, dim3(8192), dim3(256), 0, 0, a, o, n); });
     return 0;

@@ -667,3 +667,27 @@ def test_more_than_65535_heads_run_in_batch_slices():
     ref = torch.cat([fastmax(q[i:i + 30000], k[i:i + 30000], v[i:i + 30000], p=2) for i in range(0, 70000, 30000)])
     assert o.shape == q.shape and torch.equal(o, ref)
     assert fastmax_hack(q, k, v, p=1).shape == q.shape
+
+
+@pytest.mark.parametrize("p,mask", [(1, True), (2, True), (2, False)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_strided_views_give_the_same_bits_as_contiguous_tensors(p, mask, dt):
+    """(B, T, H, D) storage viewed as (B, H, T, D) (what a caller that skips the transpose copy hands over): the kernels take
+    element strides for b, h, n -- forward and backward must match the contiguous run exactly"""
+    from attention_mechanisms.fastmax import fastmax
+    g = torch.Generator().manual_seed(7)
+    B, T, H, D = 2, 640, 3, 64
+    base = [torch.randn(B, T, H, D, generator=g).to(dt).cuda() for _ in range(3)]
+    go = torch.randn(B, H, T, D, generator=g).to(dt).cuda()
+    outs = []
+    for contiguous in (False, True):
+        q, k, v = (t.permute(0, 2, 1, 3) for t in base)
+        if contiguous:
+            q, k, v = (t.contiguous() for t in (q, k, v))
+        q, k, v = (t.detach().requires_grad_(True) for t in (q, k, v))
+        assert q.is_contiguous() == contiguous
+        o = fastmax(q, k, v, mask=mask, p=p)
+        o.backward(go.to(o.dtype))
+        outs.append([o.detach(), q.grad, k.grad, v.grad])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

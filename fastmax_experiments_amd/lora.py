@@ -99,11 +99,13 @@ class NF4Linear(nn.Module):
         packed, absmax = nf4_quantize(w)
         qs = [absmax, torch.Size(w.shape), w.dtype, BLOCK, None, "nf4"]
         self.weight = Params4bit(packed, qs)
+        self._dense_cache = None
         if bias is not None:
             self.bias = nn.Parameter(bias.detach().float().clone(), requires_grad=False)
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)
+        self._dense_cache = None                                                          # re-enable after moving the module
         qs = self.weight.quant_state
         moved = fn(qs[0])
         qs[0] = moved if moved.dtype == torch.float32 else qs[0].to(moved.device)       # absmax stays fp32
@@ -114,6 +116,16 @@ class NF4Linear(nn.Module):
 
     def dequantize(self, dtype=torch.float32) -> torch.Tensor:
         return nf4_dequantize(self.weight.data, self.weight.quant_state[0], self.weight.quant_state[1], dtype)
+
+    # Opt-in, MI355X-specific: keep a decoded bf16 copy of the frozen weight next to the 4-bit codes.  288 GB of HBM hold
+    # the bf16 copies of a 7B model (14 GB) with room to spare; the checkpoint and the optimizer state stay 4-bit / LoRA-only,
+    # but every product becomes a plain library GEMM with no decode in the loop (2-5x at <= 2048 rows, where the fused
+    # kernel's grid cannot fill 256 CUs, and no per-call decode above).  Dropped by load_dense() / merge().
+    _dense_cache = None
+
+    def cache_dense(self, enable: bool = True):
+        self._dense_cache = self.dequantize(torch.bfloat16) if enable else None
+        return self
 
     # the block scales travel with the module state (state_dict round trips of a quantised model)
     def get_extra_state(self):
@@ -164,12 +176,13 @@ class _QLoRALinearFn(torch.autograd.Function):
     (M >= DENSE_M, bf16): HIP dequant to scratch + library GEMMs.  d(ea), d(eb) are thin library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x2, ea, eb, wq, absmax, bias, N, K):
+    def forward(ctx, x2, ea, eb, wq, absmax, bias, N, K, wdense=None):
         M = x2.shape[0]
         dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
-        ctx.dense = dt == _lib.BF16 and M >= DENSE_M
+        ctx.dense = dt == _lib.BF16 and (M >= DENSE_M or wdense is not None)
+        ctx.wdense = wdense
         if ctx.dense:
-            y = x2 @ _dense_weight(wq, absmax, N, K).t()
+            y = x2 @ (wdense if wdense is not None else _dense_weight(wq, absmax, N, K)).t()
             if ea is not None:
                 y.addmm_(ea, eb.t())
             if bias is not None:
@@ -195,7 +208,7 @@ class _QLoRALinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = d_ea = d_eb = None
         if ctx.needs_input_grad[0] and ctx.dense:
-            dx = dy @ _dense_weight(wq, absmax, N, K)
+            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, absmax, N, K))
         elif ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
             with torch.cuda.device(dy.device):
@@ -208,7 +221,7 @@ class _QLoRALinearFn(torch.autograd.Function):
                 d_ea = dyb @ eb                       # (M,N)(N,32): thin GEMM, library call
             if ctx.needs_input_grad[2]:
                 d_eb = dyb.t() @ ea                   # (N,M)(M,32)
-        return dx, d_ea, d_eb, None, None, None, None, None
+        return dx, d_ea, d_eb, None, None, None, None, None, None
 
 
 def qlora_linear(x, base: NF4Linear, ea, eb):
@@ -224,12 +237,17 @@ def qlora_linear(x, base: NF4Linear, ea, eb):
         x2 = x2.contiguous()
     if ea is not None:
         r = ea.shape[-1]
-        ea = F.pad(ea.reshape(-1, r).to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
-        eb = F.pad(eb.to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
+        library_route = cdt == torch.bfloat16 and (x2.shape[0] >= DENSE_M or base._dense_cache is not None)
+        if library_route:
+            # decode-once / cached route: the LoRA branch is a plain addmm -- no padding to the fused kernel's 32-wide k-step
+            ea, eb = ea.reshape(-1, r).to(torch.bfloat16), eb.to(torch.bfloat16)
+        else:
+            ea = F.pad(ea.reshape(-1, r).to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
+            eb = F.pad(eb.to(torch.bfloat16), (0, RANK_PAD - r)).contiguous()
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, base.weight.quant_state[0], bias, N, K)
+    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N).to(x.dtype)
 
 
@@ -392,6 +410,17 @@ def mark_only_lora_as_trainable(model: nn.Module) -> None:
 def lora_filter(key: str, value: Any) -> bool:
     """lit_gpt/lora.py:469-470."""
     return "lora_" in key
+
+
+def cache_dense_weights(model: nn.Module, enable: bool = True) -> int:
+    """Opt-in bf16 copies of every NF4Linear weight in `model` (see NF4Linear.cache_dense).  Returns the bytes held."""
+    held = 0
+    for m in model.modules():
+        if isinstance(m, NF4Linear):
+            m.cache_dense(enable)
+            if m._dense_cache is not None:
+                held += m._dense_cache.numel() * 2
+    return held
 
 
 def merge_lora_weights(model: nn.Module) -> None:

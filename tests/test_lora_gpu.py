@@ -131,3 +131,30 @@ def test_rejects_unsupported_shapes_loudly():
     q = lora.NF4Linear.from_linear(torch.nn.Linear(64, 64)).cuda()
     with pytest.raises(NotImplementedError):
         q(torch.randn(4, 64, device="cuda", dtype=torch.bfloat16))
+
+
+def test_dense_weight_cache_gives_the_decode_once_results():
+    """NF4Linear.cache_dense(): same values as the decode-once route (the cached matrix IS the decoded weight), forward and
+    input / LoRA gradients, at row counts on both sides of DENSE_M; dropped by merge()"""
+    import torch
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(0)
+    K, N = 256, 320
+    layer = lora.LoRALinear(K, N, r=8, lora_alpha=16, bias=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda()
+    for M in (16, 4096):
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        outs = []
+        for cached in (False, True):
+            layer.linear.cache_dense(cached)
+            xx = x.clone().requires_grad_(True)
+            y = layer(xx)
+            y.float().sum().backward()
+            outs.append((y.detach().float(), xx.grad.float(), layer.lora_A.grad.float().clone(), layer.lora_B.grad.float().clone()))
+            layer.lora_A.grad = layer.lora_B.grad = None
+        for a, b in zip(*outs):
+            assert (a - b).abs().max() <= 2e-2 * b.abs().max().clamp_min(1e-6)
+    assert lora.cache_dense_weights(layer) == K * N * 2
+    layer.merge()
+    assert layer.linear._dense_cache is None

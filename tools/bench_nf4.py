@@ -32,6 +32,8 @@ def main():
         torch.nn.init.normal_(layer.lora_B, std=0.02)
         dense_w = layer.linear.weight.data.to("cuda", torch.bfloat16)
         layer.quantize_base().cuda()
+        if os.environ.get("FASTMAX_NF4_CACHE") == "1":
+            layer.linear.cache_dense()
         x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
         gy = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
         with torch.no_grad():
@@ -39,12 +41,13 @@ def main():
             t_d = timeit(lambda: torch.nn.functional.linear(x, dense_w))
         wq, am = layer.linear.weight.data, layer.linear.weight.quant_state[0]
         fn = lora._QLoRALinearFn
+        wd = layer.linear._dense_cache
 
         def dx():
             xx = x.detach().requires_grad_(True)
-            y = fn.apply(xx, None, None, wq, am, None, N, K)
+            y = fn.apply(xx, None, None, wq, am, None, N, K, wd)
             y.backward(gy)
-        t_b = timeit(dx) - timeit(lambda: fn.apply(x, None, None, wq, am, None, N, K))
+        t_b = timeit(dx) - timeit(lambda: fn.apply(x, None, None, wq, am, None, N, K, wd))
         fl = 2 * M * K * N / 1e9
         print(f"| {M} | {K} | {N} | {t_f:.3f} | {fl / t_f:.0f} | {t_b:.3f} | {fl / t_b:.0f} | {t_d:.3f} | {fl / t_d:.0f} |", flush=True)
 

@@ -291,6 +291,92 @@ __global__ __launch_bounds__(256, 2) void nf4_linear_dx_kernel(Nf4Params prm) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward for a handful of rows (M <= 16: generation, one token per sequence): the 128 x 128 tile kernel would put
+// N/128 workgroups on the chip.  Here a workgroup owns 16 output columns and its four waves split K in 128-wide blocks
+// (block j -> wave j % 4); per block a lane loads 16 bytes of codes (32 weights of ONE row: A operand rows = output
+// columns) and the matching 64 bytes of x (B operand), decodes in registers and issues four MFMA 16x16x32.  The four
+// partial 16 x 16 tiles meet in LDS; wave 0 adds the LoRA k-step and the bias.  HBM-bound on the 0.5 byte / weight codes.
+// grid = N/16, block = 256.  Requires K % 128 == 0, N % 16 == 0, M <= 16.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nf4_gemv_kernel(Nf4Params prm) {
+    __shared__ float lut[16];
+    __shared__ __attribute__((aligned(16))) float part[4][16 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q4 = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int M = prm.M, N = prm.N, K = prm.K;
+    const T* X = reinterpret_cast<const T*>(prm.x);
+    if (tid < 16) lut[tid] = kNF4[tid];
+    __syncthreads();
+    const int n = n0 + r;
+    const bool mrow = r < M;
+    const T* xrow = X + (int64_t)(mrow ? r : 0) * prm.ldx;
+    f32x4 acc = {0, 0, 0, 0};
+    const int nblk = K / 128;
+    // two 128-wide blocks per trip: both blocks' codes, scales and x pieces are requested before either is decoded
+    auto fetch = [&](int j, u32x4& pk, float& amax, bf16x8 (&xf)[4]) {
+        const int64_t e = (int64_t)n * K + 128 * j + 32 * q4;             // first of this lane's 32 weights
+        pk = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(prm.wq + (e >> 1)));
+        amax = prm.absmax[e >> 6];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (mrow) xf[t] = load8_as_bf16<T>(xrow + 128 * j + 32 * q4 + 8 * t);
+            else
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xf[t][i] = (__bf16)0.0f;
+        }
+    };
+    auto consume = [&](const u32x4& pk, float amax, const bf16x8 (&xf)[4]) {
+        bf16x8 wf[4];
+        dequant32(pk, amax, lut, wf);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[t], acc, 0, 0, 0);
+    };
+    int j = w;
+    for (; j + 4 < nblk; j += 8) {
+        u32x4 pk0, pk1;
+        float a0, a1;
+        bf16x8 x0[4], x1[4];
+        fetch(j, pk0, a0, x0);
+        fetch(j + 4, pk1, a1, x1);
+        consume(pk0, a0, x0);
+        consume(pk1, a1, x1);
+    }
+    if (j < nblk) {
+        u32x4 pk0;
+        float a0;
+        bf16x8 x0[4];
+        fetch(j, pk0, a0, x0);
+        consume(pk0, a0, x0);
+    }
+    // C layout: column (lane & 15) = row m of x, rows 4 q4 + i = output column n0 + 4 q4 + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[w][(4 * q4 + i) * 16 + r] = acc[i];
+    __syncthreads();
+    if (w == 0) {
+        f32x4 tot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            tot[i] = (part[0][(4 * q4 + i) * 16 + r] + part[1][(4 * q4 + i) * 16 + r]) + (part[2][(4 * q4 + i) * 16 + r] + part[3][(4 * q4 + i) * 16 + r]);
+        if (prm.ea) {
+            bf16x8 af = *reinterpret_cast<const bf16x8*>(prm.eb + (int64_t)n * 32 + 8 * q4), bf;
+            if (mrow) bf = *reinterpret_cast<const bf16x8*>(prm.ea + (int64_t)r * 32 + 8 * q4);
+            else
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bf[i] = (__bf16)0.0f;
+            tot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, tot, 0, 0, 0);
+        }
+        if (prm.bias) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(prm.bias + n0 + 4 * q4);
+            tot += b4;
+        }
+        if (mrow) store4<T>(reinterpret_cast<T*>(prm.y) + (int64_t)r * prm.ldy + n0 + 4 * q4, tot);
+    }
+}
+
 // ---- dequantise to a dense matrix: the merge path (lora.py:142-168) and the large-M route of the QLoRA linear, where
 // the W tile would otherwise be re-decoded by every one of the M/128 workgroup rows: decode once, then a plain GEMM.
 // One thread = 16 packed bytes = 32 codes = half a quantisation block (one absmax); bf16 out = 4 x 16-byte stores.
@@ -346,6 +432,14 @@ int fastmax_hip_nf4_linear_forward(const void* x, int64_t ldx, const uint8_t* wq
     Nf4Params p{x, wq, absmax, bias, reinterpret_cast<const __bf16*>(ea), reinterpret_cast<const __bf16*>(eb), y, M, N, K,
                 ldx, ldy};
     dim3 grid((N + 127) / 128, (M + 127) / 128), block(256);
+    if (M <= 16 && (K % 128) == 0 && (N % 16) == 0 && (!bias || !(reinterpret_cast<uintptr_t>(bias) & 15)) &&
+        (!ea || !((reinterpret_cast<uintptr_t>(ea) | reinterpret_cast<uintptr_t>(eb)) & 15))) {
+        // generation-size row counts: column-sliced kernel that fills the chip (N/16 workgroups)
+        if (dtype == FASTMAX_BF16) hipLaunchKernelGGL(nf4_gemv_kernel<__bf16>, dim3(N / 16), block, 0, (hipStream_t)stream, p);
+        else if (dtype == FASTMAX_F32) hipLaunchKernelGGL(nf4_gemv_kernel<float>, dim3(N / 16), block, 0, (hipStream_t)stream, p);
+        else return FASTMAX_E_BAD_DTYPE;
+        return (int)hipGetLastError();
+    }
     if (dtype == FASTMAX_BF16) hipLaunchKernelGGL(nf4_linear_fwd_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, p);
     else if (dtype == FASTMAX_F32) hipLaunchKernelGGL(nf4_linear_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     else return FASTMAX_E_BAD_DTYPE;

@@ -30,7 +30,8 @@ def test_hip_dequantize_matches_codec_bit_for_bit():
     assert torch.equal(dev16.cpu(), host.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (128, 128, 64), (1000, 512, 1088), (77, 2048, 2560)])
+@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (128, 128, 64), (1000, 512, 1088), (77, 2048, 2560), (1, 4096, 4096), (5, 1408, 320),
+                                   (16, 2048, 2560)])          # M <= 16: the column-sliced generation kernel
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_nf4_linear_forward_and_dx(M, K, N, dt):
     from fastmax_experiments_amd import lora
@@ -158,3 +159,20 @@ def test_dense_weight_cache_gives_the_decode_once_results():
     assert lora.cache_dense_weights(layer) == K * N * 2
     layer.merge()
     assert layer.linear._dense_cache is None
+
+
+@pytest.mark.parametrize("M", [1, 3, 16])
+def test_generation_size_rows_with_lora_branch_and_bias(M):
+    """M <= 16 takes nf4_gemv_kernel (LoRA k-step and bias in its epilogue): same function as the dense reference"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(M)
+    K, N = 1024, 768
+    layer = lora.LoRALinear(K, N, r=8, lora_alpha=16, bias=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    torch.nn.init.normal_(layer.linear.bias, std=0.5)
+    layer.quantize_base().cuda()
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        y = layer(x)
+    ref = _dense_reference(layer, x)
+    assert y.shape == (M, N) and _rel(y, ref) < 1.5e-2

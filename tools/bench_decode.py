@@ -38,3 +38,25 @@ for B, H, T, D in ((1, 32, 4096, 64), (1, 32, 16384, 128), (8, 32, 4096, 64)):
     with torch.no_grad():
         ms = timeit(lambda: st.step(q1, k1, v1))
     print(f"| decode state cache step (p=1, opt-in) | ({B},{H},1,{T},{D}) | bfloat16 | 1 | {ms:.4f} |", flush=True)
+
+# the frozen 4-bit linear at generation-size row counts (merged weights: no LoRA branch), eager and as a HIP graph replay
+from fastmax_experiments_amd import lora
+for M, K, N in ((1, 4096, 4096), (16, 4096, 4096), (1, 4096, 11008), (1, 11008, 4096)):
+    lin = torch.nn.Linear(K, N, bias=False)
+    q4 = lora.NF4Linear.from_linear(lin).cuda()
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    wd = q4.dequantize(torch.bfloat16)
+    with torch.no_grad():
+        t_e = timeit(lambda: q4(x))
+        t_d = timeit(lambda: torch.nn.functional.linear(x, wd))
+        q4(x)
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            q4(x)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(10):
+                y = q4(x)
+        t_g = timeit(lambda: graph.replay()) / 10
+    print(f"| NF4 linear (M,K,N)=({M},{K},{N}): eager {t_e * 1e3:.1f} us, graph replay {t_g * 1e3:.1f} us = {N * K / 2 / t_g / 1e6:.0f} GB/s of codes; bf16 F.linear {t_d * 1e3:.1f} us | | bfloat16 | | {t_g:.4f} |", flush=True)

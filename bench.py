@@ -95,6 +95,17 @@ def cpu_baseline(args, seconds):
     }
 
 
+def _baseline_metric():
+    """the metric string of BASELINE.json (kept verbatim so the line can be matched against it)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "fastmax attn tokens/sec + achieved HBM GB/s at N=4096 d=64, 1/8 GPU"
+
+
+METRIC = _baseline_metric()
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE JSON line (rank 0).  Libraries write there too -- the image exports NCCL_DEBUG=VERSION and RCCL
@@ -194,7 +205,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "fastmax attn tokens/sec + achieved HBM GB/s at N=4096 d=64",
+            "metric": METRIC,
             "value": round(world * B * N * args.steps / elapsed, 1),
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -22,7 +22,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_decode_state_bytes", "fastmax_hip_p1_prefill_state", "fastmax_hip_p1_decode_step",
            "fastmax_hip_normalize_stats", "fastmax_hip_normalize_cast", "fastmax_hip_normalize_backward_workspace",
            "fastmax_hip_normalize_backward", "fastmax_hip_rope_qkv_split", "fastmax_hip_rope_qkv_split_backward", "fastmax_hip_cross_entropy_forward", "fastmax_hip_cross_entropy_backward",
-           "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize"]
+           "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize",
+           "fastmax_hip_lora_down", "fastmax_hip_lora_tn_workspace", "fastmax_hip_lora_tn", "fastmax_hip_lora_up"]
 
 
 class Problem(ctypes.Structure):
@@ -93,12 +94,20 @@ def lib():
     L.fastmax_hip_nf4_linear_backward_input.restype = ci
     L.fastmax_hip_nf4_dequantize.argtypes = [vp, vp, vp, i64, ci, vp]
     L.fastmax_hip_nf4_dequantize.restype = ci
+    L.fastmax_hip_lora_down.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, ci, vp]
+    L.fastmax_hip_lora_down.restype = ci
+    L.fastmax_hip_lora_tn_workspace.argtypes = [ci, ci, ci]
+    L.fastmax_hip_lora_tn_workspace.restype = i64
+    L.fastmax_hip_lora_tn.argtypes = [vp, i64, vp, i64, vp, ci, ci, ci, vp, ci, ci, ci, vp]
+    L.fastmax_hip_lora_tn.restype = ci
+    L.fastmax_hip_lora_up.argtypes = [vp, i64, vp, i64, vp, i64, vp, ci, ci, ci, vp]
+    L.fastmax_hip_lora_up.restype = ci
     L.fastmax_hip_abi_version.restype = ci
     L.fastmax_hip_select_path.argtypes = [pp]
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 2:
+    if L.fastmax_hip_abi_version() != 3:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

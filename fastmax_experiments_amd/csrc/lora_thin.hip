@@ -1,0 +1,460 @@
+// The low-rank branch of the QLoRA linear at training sizes (reference: lit_gpt/lora.py:170-177 LoRALinear.forward,
+// :398-433 LoRAQKVLinear.forward, and the autograd mirror of those lines).  With the frozen base product on the library
+// GEMM (M >= 2048 rows), what is left of the layer are rank-r products that each stream one (M x K) or (M x N) bf16
+// matrix once -- HBM-bound passes, one kernel each:
+//     down : E[M][RP]   = X[M][K] . Bt[RP][K]^T            ea = x A^T          d_ea = dy eb
+//            (+ E^T, zero padded, for the next kernel)
+//     tn   : C[RP][N]   = E^T[RP][M] . X[M][N]   (fp32)    d_eb^T = ea^T dy    dA = d_ea^T x
+//     up   : Y[M][N]   += E[M][R] . Bn[N][R]^T (+ bias)    y += ea eb^T        dx += d_ea A
+// All operands bf16, fp32 accumulation.  RP = rank padded to 16 or 32 (zero columns).
+//   down: one workgroup per 16 rows, the 4 waves split K in interleaved 64-column steps (two 16x16x32 MFMA k-steps, each
+//         load instruction takes 64 contiguous bytes of 16 rows), cross-wave sum through LDS.
+//   tn  : the contraction runs down the rows of X, so 64-row x 64-column tiles are staged in an LDS image and read with
+//         ds_read_b64_tr_b16 (the same transposed fragment the fastmax state kernels use); workgroups own a 64-column slab
+//         and a range of rows, X tiles are fetched two stages ahead; per-range partials are summed (and cast / transposed)
+//         by a second small kernel in a fixed order.
+//   up  : read-modify-write of Y with 16-byte accesses, lane = 8 (or 4) consecutive columns, wave = one row per step;
+//         the row's R coefficients are wave-uniform (one dword per lane + v_readlane), Bn lives in registers.  As many waves
+//         as the device holds at once, each walking its column slab with two row blocks in flight.
+//         16 R FMAs per 16 bytes: VALU, under the HBM time.
+#include <stdlib.h>
+
+#include "fastmax_mfma_common.h"
+
+namespace fastmax {
+
+typedef unsigned int tu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tu32x2 __attribute__((ext_vector_type(2)));
+
+// plain loads: every matrix streamed here is read again by the next kernel of the layer (measured: with non-temporal
+// loads of y the RoPE pass that follows ran 15 us slower)
+#ifdef THIN_NT
+#define THIN_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define THIN_STREAM_LOAD(p) (*(p))
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// down
+// ---------------------------------------------------------------------------------------------------------------------
+struct DownParams {
+    const __bf16* x; int64_t ldx;
+    const __bf16* bt; int64_t ldbt;
+    __bf16* e; int64_t lde;
+    __bf16* et; int64_t ldet;      // may be null
+    int M, K;
+};
+
+template <int RPB>   // RP = 16 RPB
+__global__ __launch_bounds__(256) void lora_down_kernel(const DownParams p) {
+    __shared__ float red[4][RPB][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int m = m0 + r;
+    const bool live = m < p.M;
+    const __bf16* xr = p.x + (int64_t)(live ? m : 0) * p.ldx + 8 * q;
+    const __bf16* br = p.bt + (int64_t)r * p.ldbt + 8 * q;
+    f32x4 acc[RPB];
+#pragma unroll
+    for (int cb = 0; cb < RPB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nstep = p.K >> 6;
+    struct Step { tu32x4 x0, x1; bf16x8 b0[RPB], b1[RPB]; };
+    auto fetch = [&](int d, Step& t) {
+        const int kb = d << 6;
+        t.x0 = tu32x4{0, 0, 0, 0};
+        t.x1 = tu32x4{0, 0, 0, 0};
+        if (live) {
+            t.x0 = THIN_STREAM_LOAD(reinterpret_cast<const tu32x4*>(xr + kb));
+            t.x1 = THIN_STREAM_LOAD(reinterpret_cast<const tu32x4*>(xr + kb + 32));
+        }
+#pragma unroll
+        for (int cb = 0; cb < RPB; ++cb) {
+            t.b0[cb] = *reinterpret_cast<const bf16x8*>(br + (int64_t)cb * 16 * p.ldbt + kb);
+            t.b1[cb] = *reinterpret_cast<const bf16x8*>(br + (int64_t)cb * 16 * p.ldbt + kb + 32);
+        }
+    };
+    auto consume = [&](const Step& t) {
+#pragma unroll
+        for (int cb = 0; cb < RPB; ++cb) {
+            acc[cb] = mfma(__builtin_bit_cast(bf16x8, t.x0), t.b0[cb], acc[cb]);
+            acc[cb] = mfma(__builtin_bit_cast(bf16x8, t.x1), t.b1[cb], acc[cb]);
+        }
+    };
+    // this wave's steps are wave, wave + 4, ...; the sweep starts at a column that depends on the workgroup so that the
+    // resident workgroups do not all walk the same columns (the same memory channels) at the same time
+    const int nj = (nstep - wave + 3) >> 2;
+    const int rot = nj > 0 ? (int)(blockIdx.x % (unsigned)nj) : 0;
+    auto col = [&](int j) { int jj = j + rot; if (jj >= nj) jj -= nj; return wave + 4 * jj; };
+    int j = 0;
+    for (; j + 3 < nj; j += 4) {               // four steps of this wave in flight
+        Step t0, t1, t2, t3;
+        fetch(col(j), t0);
+        fetch(col(j + 1), t1);
+        fetch(col(j + 2), t2);
+        fetch(col(j + 3), t3);
+        consume(t0);
+        consume(t1);
+        consume(t2);
+        consume(t3);
+    }
+    for (; j < nj; ++j) {
+        Step t;
+        fetch(col(j), t);
+        consume(t);
+    }
+#pragma unroll
+    for (int cb = 0; cb < RPB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][cb][i][lane] = acc[cb][i];
+    __syncthreads();
+    {
+        const int i = tid >> 6, l = tid & 63;           // accumulator register i of lane l: row 4 (l>>4) + i, column l & 15
+        const int row = m0 + 4 * (l >> 4) + i, col = l & 15;
+#pragma unroll
+        for (int cb = 0; cb < RPB; ++cb) {
+            const float s = (red[0][cb][i][l] + red[1][cb][i][l]) + (red[2][cb][i][l] + red[3][cb][i][l]);
+            const __bf16 v = (__bf16)s;
+            if (row < p.M) p.e[(int64_t)row * p.lde + cb * 16 + col] = v;
+            if (p.et) p.et[(int64_t)(cb * 16 + col) * p.ldet + row] = row < p.M ? v : (__bf16)0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tn
+// ---------------------------------------------------------------------------------------------------------------------
+struct TnParams {
+    const __bf16* et; int64_t ldet; int etcols;    // columns >= M up to etcols are zero; etcols % 4 == 0
+    const __bf16* x; int64_t ldx;
+    float* part;                                   // (S, RP, ncols)
+    int M, ncols, rps;                             // rows per split, a whole number of stages
+};
+
+template <int RPB, int KS>   // stages of 32 KS rows
+__global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * KS * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 64, s = blockIdx.y;
+    const int mbeg = s * p.rps, mend = min(p.M, mbeg + p.rps);
+    constexpr int SR = 32 * KS, SB = SR * 128;
+    const int nst = (mend - mbeg + SR - 1) / SR;
+    f32x4 acc[RPB];
+#pragma unroll
+    for (int cb = 0; cb < RPB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct XRegs { tu32x4 v[KS]; };
+    tu32x2 ar[RPB][KS][2];
+    // X tiles are fetched two stages ahead (two register sets), the small E^T fragments one stage ahead
+    auto fetch_x = [&](int st, XRegs& x) {
+        const int mb = mbeg + st * SR;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int piece = tid + 256 * i, row = piece >> 3, chunk = piece & 7;
+            x.v[i] = tu32x4{0, 0, 0, 0};
+            if (mb + row < mend) x.v[i] = THIN_STREAM_LOAD(reinterpret_cast<const tu32x4*>(p.x + (int64_t)(mb + row) * p.ldx + n0 + 8 * chunk));
+        }
+    };
+    auto fetch_a = [&](int st) {
+        const int mb = mbeg + st * SR;
+#pragma unroll
+        for (int cb = 0; cb < RPB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int mm = mb + 32 * ks + 16 * h + 4 * q;      // the k order of ld_tr8: rows 4q+{0..3}, 16+4q+{0..3}
+                    ar[cb][ks][h] = tu32x2{0, 0};
+                    if (mm < mend && mm + 4 <= p.etcols) ar[cb][ks][h] = *reinterpret_cast<const tu32x2*>(p.et + (int64_t)(cb * 16 + r) * p.ldet + mm);
+                }
+    };
+    auto stage = [&](const XRegs& x, int buf) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int piece = tid + 256 * i, row = piece >> 3, chunk = piece & 7;
+            *reinterpret_cast<tu32x4*>(smem + buf * SB + img_off<64>(row, chunk)) = x.v[i];
+        }
+    };
+    auto step = [&](int st, const XRegs& xnext, XRegs& xfree) {
+        const int buf = st & 1;
+        tu32x2 a[RPB][KS][2];
+#pragma unroll
+        for (int cb = 0; cb < RPB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { a[cb][ks][0] = ar[cb][ks][0]; a[cb][ks][1] = ar[cb][ks][1]; }
+        if (st + 1 < nst) fetch_a(st + 1);
+        if (st + 2 < nst) fetch_x(st + 2, xfree);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 b = ld_tr8<64>(smem, buf * SB, 32 * ks, 16 * wave, lane);
+#pragma unroll
+            for (int cb = 0; cb < RPB; ++cb) {
+                union { bf16x8 v; tu32x2 h[2]; } u;
+                u.h[0] = a[cb][ks][0];
+                u.h[1] = a[cb][ks][1];
+                acc[cb] = mfma(u.v, b, acc[cb]);
+            }
+        }
+        if (st + 1 < nst) stage(xnext, buf ^ 1);
+        __syncthreads();
+    };
+    XRegs xa, xb;
+    if (nst > 0) {
+        fetch_x(0, xa);
+        if (nst > 1) fetch_x(1, xb);
+        fetch_a(0);
+        stage(xa, 0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; st += 2) {
+        step(st, xb, xa);
+        if (st + 1 < nst) step(st + 1, xa, xb);
+    }
+    // C: column n = 16 wave + (lane & 15), row c = 16 cb + 4 q + i
+    float* out = p.part + ((int64_t)s * RPB * 16) * p.ncols + n0 + 16 * wave + r;
+#pragma unroll
+    for (int cb = 0; cb < RPB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(int64_t)(cb * 16 + 4 * q + i) * p.ncols] = acc[cb][i];
+}
+
+// out[c][n] (or out[n][c] when transposed) = sum_s part[s][c][n] for c < R, summed in split order; float32 or bf16
+__global__ __launch_bounds__(256) void lora_tn_reduce_kernel(const float* part, void* out, int S, int RP, int R, int ncols, int out_bf16,
+                                                             int transpose) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)R * ncols) return;
+    const int c = (int)(i / ncols), n = (int)(i % ncols);
+    const int64_t plane = (int64_t)RP * ncols;
+    const float* src = part + (int64_t)c * ncols + n;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + u) * plane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < S; ++k) s += src[(int64_t)k * plane];
+    const int64_t o = transpose ? (int64_t)n * R + c : i;
+    if (out_bf16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)s;
+    else reinterpret_cast<float*>(out)[o] = s;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int tn_ks() { static const int ks = env_int("FASTMAX_LORA_TN_KS", 2) == 4 ? 4 : 2; return ks; }
+
+static void tn_plan(int M, int ncols, int& S, int& rps) {
+    static const int target = env_int("FASTMAX_LORA_TN_TARGET", 1024);
+    const int slabs = ncols / 64, sr = 32 * tn_ks();
+    int want = (target + slabs - 1) / slabs;
+    const int maxs = (M + sr - 1) / sr;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    rps = (((M + want - 1) / want) + sr - 1) / sr * sr;
+    S = (M + rps - 1) / rps;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// up
+// ---------------------------------------------------------------------------------------------------------------------
+struct UpParams {
+    __bf16* y; int64_t ldy;
+    const __bf16* e; int64_t lde;
+    const __bf16* bn; int64_t ldb;
+    const float* bias;             // may be null
+    int M, N, nslab, groups;       // groups: waves per column slab
+};
+
+template <int NPL> struct UpVec;
+template <> struct UpVec<8> { typedef tu32x4 type; };
+template <> struct UpVec<4> { typedef tu32x2 type; };
+
+__device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Each wave keeps one slab of 64 NPL columns (its Bn rows stay in registers) and walks row blocks of RU rows with a stride
+// of `groups` blocks, two blocks in flight: the loads of block i+1 are issued before block i is finished.  The block's
+// RU x R coefficients are fetched with one dword per lane and broadcast with v_readlane.
+template <int R, int NPL, int RU>
+__global__ __launch_bounds__(256) void lora_up_kernel(const UpParams p) {
+    typedef typename UpVec<NPL>::type vec_t;
+    static_assert(RU * R / 2 <= 64, "one dword of E per lane");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= p.nslab * p.groups) return;
+    const int slab = w % p.nslab, g = w / p.nslab;
+    const int n = slab * 64 * NPL + lane * NPL;
+    const bool act = n < p.N;
+    const int nn = act ? n : 0;                                              // idle lanes read column 0 and store nothing
+    const int nblk = (p.M + RU - 1) / RU;
+    float b[NPL][R], bias[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        bias[j] = p.bias ? p.bias[nn + j] : 0.f;
+#pragma unroll
+        for (int c = 0; c < R; c += 8) {
+            const tu32x4 wv = *reinterpret_cast<const tu32x4*>(p.bn + (int64_t)(nn + j) * p.ldb + c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                b[j][c + 2 * t] = bf_lo(wv[t]);
+                b[j][c + 2 * t + 1] = bf_hi(wv[t]);
+            }
+        }
+    }
+    struct Blk { vec_t y[RU]; unsigned int e; };
+    const int eu = lane / (R / 2), ec = lane % (R / 2);                      // this lane's dword of the block's coefficients
+    auto fetch = [&](int bi, Blk& t) {
+        const int m = bi * RU;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            t.y[u] = vec_t{};
+            if (act && m + u < p.M) t.y[u] = THIN_STREAM_LOAD(reinterpret_cast<const vec_t*>(p.y + (int64_t)(m + u) * p.ldy + n));
+        }
+        t.e = 0;
+        if (eu < RU && m + eu < p.M) t.e = *reinterpret_cast<const unsigned int*>(p.e + (int64_t)(m + eu) * p.lde + 2 * ec);
+    };
+    auto finish = [&](int bi, const Blk& t) {
+        const int m = bi * RU;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            float o[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; j += 2) {
+                const unsigned int wv = t.y[u][j >> 1];
+                o[j] = bf_lo(wv) + bias[j];
+                o[j + 1] = bf_hi(wv) + bias[j + 1];
+            }
+#pragma unroll
+            for (int c = 0; c < R; c += 2) {
+                const unsigned int wv = __builtin_amdgcn_readlane(t.e, u * (R / 2) + (c >> 1));
+                const float e0 = bf_lo(wv), e1 = bf_hi(wv);
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) o[j] = fmaf(e1, b[j][c + 1], fmaf(e0, b[j][c], o[j]));
+            }
+            vec_t ov;
+#pragma unroll
+            for (int j = 0; j < NPL; j += 2)
+                ov[j >> 1] = (unsigned int)f32_to_bf16_bits(o[j]) | ((unsigned int)f32_to_bf16_bits(o[j + 1]) << 16);
+            if (act && m + u < p.M) *reinterpret_cast<vec_t*>(p.y + (int64_t)(m + u) * p.ldy + n) = ov;
+        }
+    };
+    const int G = p.groups;
+    Blk ba, bb;
+    int bi = g;
+    if (bi < nblk) fetch(bi, ba);
+    for (; bi < nblk; bi += 2 * G) {
+        if (bi + G < nblk) fetch(bi + G, bb);
+        finish(bi, ba);
+        if (bi + 2 * G < nblk) fetch(bi + 2 * G, ba);
+        if (bi + G < nblk) finish(bi + G, bb);
+    }
+}
+
+template <int R, int NPL, int RU> static int up_launch(UpParams p, hipStream_t stream) {
+    static int resident = 0;                          // waves of this kernel the device holds at once
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lora_up_kernel<R, NPL, RU>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = per_cu * cus * 4 * env_int("FASTMAX_LORA_UP_OVERSUB", 1);
+    }
+    p.nslab = (p.N + 64 * NPL - 1) / (64 * NPL);
+    const int nblk = (p.M + RU - 1) / RU;
+    int groups = resident / p.nslab;
+    if (groups < 1) groups = 1;
+    if (groups > nblk) groups = nblk;
+    p.groups = groups;
+    const int64_t waves = (int64_t)p.nslab * groups;
+    hipLaunchKernelGGL((lora_up_kernel<R, NPL, RU>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+static bool aligned16(const void* ptr, int64_t ld_elems) { return !(reinterpret_cast<uintptr_t>(ptr) & 15) && (ld_elems * 2) % 16 == 0; }
+
+}  // namespace fastmax
+
+using namespace fastmax;
+
+extern "C" {
+
+int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
+                          int64_t ldet, int M, int K, int RP, void* stream) {
+    if (!x || !bt || !e) return FASTMAX_E_NULL;
+    if (M <= 0 || K <= 0 || K % 64 || (RP != 16 && RP != 32) || lde < RP || ldx < K || ldbt < K) return FASTMAX_E_BAD_SHAPE;
+    if (!aligned16(x, ldx) || !aligned16(bt, ldbt)) return FASTMAX_E_BAD_SHAPE;
+    int rows = M;
+    if (et) {
+        if (ldet < (M + 15) / 16 * 16) return FASTMAX_E_BAD_SHAPE;
+        rows = (int)(ldet / 16 * 16);                   // the transposed copy is zero filled up to its leading dimension
+    }
+    DownParams p{reinterpret_cast<const __bf16*>(x), ldx, reinterpret_cast<const __bf16*>(bt), ldbt, reinterpret_cast<__bf16*>(e), lde,
+                 reinterpret_cast<__bf16*>(et), ldet, M, K};
+    const dim3 grid((rows + 15) / 16);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (RP == 16) hipLaunchKernelGGL((lora_down_kernel<1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((lora_down_kernel<2>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int64_t fastmax_hip_lora_tn_workspace(int M, int ncols, int RP) {
+    if (M <= 0 || ncols <= 0 || ncols % 64 || (RP != 16 && RP != 32)) return -1;
+    int S, rps;
+    tn_plan(M, ncols, S, rps);
+    return (int64_t)S * RP * ncols * 4;
+}
+
+int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose, int R,
+                        void* workspace, int M, int ncols, int RP, void* stream) {
+    if (!et || !x || !out || !workspace) return FASTMAX_E_NULL;
+    if (M <= 0 || ncols <= 0 || ncols % 64 || (RP != 16 && RP != 32) || ldx < ncols || R <= 0 || R > RP) return FASTMAX_E_BAD_SHAPE;
+    if (out_dtype != FASTMAX_F32 && out_dtype != FASTMAX_BF16) return FASTMAX_E_BAD_DTYPE;
+    const int etcols = (M + 15) / 16 * 16;
+    if (ldet < etcols || (ldet * 2) % 8 || (reinterpret_cast<uintptr_t>(et) & 7) || !aligned16(x, ldx)) return FASTMAX_E_BAD_SHAPE;
+    int S, rps;
+    tn_plan(M, ncols, S, rps);
+    TnParams p{reinterpret_cast<const __bf16*>(et), ldet, etcols, reinterpret_cast<const __bf16*>(x), ldx, reinterpret_cast<float*>(workspace),
+               M, ncols, rps};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(ncols / 64, S);
+    if (tn_ks() == 4) {
+        if (RP == 16) hipLaunchKernelGGL((lora_tn_kernel<1, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((lora_tn_kernel<2, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        if (RP == 16) hipLaunchKernelGGL((lora_tn_kernel<1, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((lora_tn_kernel<2, 2>), grid, dim3(256), 0, s, p);
+    }
+    const int64_t n = (int64_t)R * ncols;
+    hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), out, S,
+                       RP, R, ncols, out_dtype == FASTMAX_BF16, transpose);
+    return (int)hipGetLastError();
+}
+
+int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, const float* bias, int M,
+                        int N, int R, void* stream) {
+    if (!y || !e || !bn) return FASTMAX_E_NULL;
+    if (M <= 0 || N <= 0 || N % 8 || ldy < N || lde < R || ldb < R) return FASTMAX_E_BAD_SHAPE;
+    if (!aligned16(y, ldy) || !aligned16(e, lde) || !aligned16(bn, ldb)) return FASTMAX_E_BAD_SHAPE;
+    UpParams p{reinterpret_cast<__bf16*>(y), ldy, reinterpret_cast<const __bf16*>(e), lde, reinterpret_cast<const __bf16*>(bn), ldb, bias, M, N, 0, 0};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int variant = env_int("FASTMAX_LORA_UP_VARIANT", 0);
+    switch (R) {
+        case 8: return variant & 1 ? up_launch<8, 8, 8>(p, s) : up_launch<8, 8, 4>(p, s);
+        case 16:
+            switch (variant) {
+                case 1: return up_launch<16, 4, 8>(p, s);
+                case 2: return up_launch<16, 4, 4>(p, s);
+                case 3: return up_launch<16, 8, 8>(p, s);
+                default: return up_launch<16, 8, 4>(p, s);
+            }
+        case 24: return up_launch<24, 4, 4>(p, s);
+        case 32: return up_launch<32, 4, 4>(p, s);
+    }
+    return FASTMAX_E_BAD_SHAPE;
+}
+
+}  // extern "C"

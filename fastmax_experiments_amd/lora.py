@@ -224,6 +224,123 @@ class _QLoRALinearFn(torch.autograd.Function):
         return dx, d_ea, d_eb, None, None, None, None, None, None
 
 
+# ---- rank-r products around the library GEMM (csrc/lora_thin.hip) ------------------------------------------------
+LORA_THIN = os.environ.get("FASTMAX_LORA_THIN", "1") != "0"
+
+
+def _pad_rank(r: int) -> int:
+    return 16 if r <= 16 else 32
+
+
+def lora_down(x: torch.Tensor, bt: torch.Tensor, want_t: bool = True):
+    """e (M, RP) = x (M, K) bt (RP, K)^T, and e^T (RP, roundup(M, 16)) zero padded; bf16."""
+    M, K = x.shape
+    RP = bt.shape[0]
+    e = torch.empty((M, RP), dtype=torch.bfloat16, device=x.device)
+    MP = (M + 15) // 16 * 16
+    et = torch.empty((RP, MP), dtype=torch.bfloat16, device=x.device) if want_t else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().fastmax_hip_lora_down(x.data_ptr(), x.stride(0), bt.data_ptr(), bt.stride(0), e.data_ptr(), RP,
+                                              None if et is None else et.data_ptr(), MP, M, K, RP, _stream(x.device))
+    _lib.check(rc, "fastmax_hip_lora_down")
+    return e, et
+
+
+def lora_tn(et: torch.Tensor, x: torch.Tensor, R: int = None, dtype=torch.float32, transpose: bool = False) -> torch.Tensor:
+    """et[:R] (R, M) x (M, ncols) -> (R, ncols), or (ncols, R) when ``transpose``; float32 sums, result float32 or bf16."""
+    M, ncols = x.shape
+    RP = et.shape[0]
+    R = RP if R is None else R
+    L = _lib.lib()
+    nb = L.fastmax_hip_lora_tn_workspace(M, ncols, RP)
+    if nb < 0:
+        raise NotImplementedError(f"lora_tn: unsupported shape M={M} ncols={ncols} RP={RP}")
+    kdt = torch.bfloat16 if dtype == torch.bfloat16 else torch.float32
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    out = torch.empty((ncols, R) if transpose else (R, ncols), dtype=kdt, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.fastmax_hip_lora_tn(et.data_ptr(), et.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                                   _lib.BF16 if kdt == torch.bfloat16 else _lib.F32, int(transpose), R, ws.data_ptr(),
+                                   M, ncols, RP, _stream(x.device))
+    _lib.check(rc, "fastmax_hip_lora_tn")
+    return out if dtype == kdt else out.to(dtype)
+
+
+def lora_up_(y: torch.Tensor, e: torch.Tensor, bn: torch.Tensor, bias=None) -> torch.Tensor:
+    """y (M, N) += e (M, R) bn (N, R)^T (+ bias), in place; bf16, bias float32."""
+    M, N = y.shape
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().fastmax_hip_lora_up(y.data_ptr(), y.stride(0), e.data_ptr(), e.stride(0), bn.data_ptr(), bn.stride(0),
+                                            None if bias is None else bias.data_ptr(), M, N, e.shape[1], _stream(y.device))
+    _lib.check(rc, "fastmax_hip_lora_up")
+    return y
+
+
+class _QLoRAThinFn(torch.autograd.Function):
+    """The many-rows route with the LoRA branch in libfastmax_hip.so: y = x deq(W)^T + bias + (x A^T) eb^T.
+    Base products are library GEMMs on the decoded (or cached) weight; the rank-r products are lora_down / lora_tn / lora_up,
+    one streaming pass each (lit_gpt/lora.py:170-177, 419-433 and their autograd mirror, without dropout)."""
+
+    @staticmethod
+    def forward(ctx, x2, A, eb, wq, absmax, bias, N, K, wdense):
+        R = A.shape[0]
+        RP = _pad_rank(R)
+        if R == RP:                                   # no padding needed: use the operands as they are
+            abt, ebp = A.to(torch.bfloat16).contiguous(), eb.to(torch.bfloat16).contiguous()
+        else:
+            abt = torch.zeros((RP, K), dtype=torch.bfloat16, device=x2.device)
+            abt[:R] = A
+            ebp = torch.zeros((N, RP), dtype=torch.bfloat16, device=x2.device)
+            ebp[:, :R] = eb
+        y = x2 @ (wdense if wdense is not None else _dense_weight(wq, absmax, N, K)).t()
+        ea, eat = lora_down(x2, abt)
+        lora_up_(y, ea, ebp, bias)
+        ctx.save_for_backward(x2, eat, abt, ebp, wq, absmax)
+        ctx.wdense = wdense
+        ctx.dims = (N, K, R, A.dtype, eb.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, eat, abt, ebp, wq, absmax = ctx.saved_tensors
+        N, K, R, a_dt, eb_dt = ctx.dims
+        dy = dy.contiguous()
+        dx = dA = d_eb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_ea, d_eat = lora_down(dy, ebp.t().contiguous())
+        if ctx.needs_input_grad[0]:
+            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, absmax, N, K))
+            lora_up_(dx, d_ea, abt.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            dA = lora_tn(d_eat, x2, R, a_dt)
+        if ctx.needs_input_grad[2]:
+            d_eb = lora_tn(eat, dy, R, eb_dt, transpose=True)
+        return dx, dA, d_eb, None, None, None, None, None, None
+
+
+def thin_route(x: torch.Tensor, base: "NF4Linear") -> bool:
+    """Does this input take the library-GEMM route with the HIP rank-r kernels?"""
+    if not LORA_THIN or x.device.type != "cuda" or x.dtype != torch.bfloat16:
+        return False
+    M = x.numel() // x.shape[-1]
+    return M >= DENSE_M or base._dense_cache is not None
+
+
+def qlora_linear_thin(x, base: "NF4Linear", A, eb):
+    """x: (..., K) bf16 device tensor; A: (r, K); eb: (N, r) with the scaling applied."""
+    N, K = base.out_features, base.in_features
+    if K % 128 or N % 64:
+        raise NotImplementedError(f"fused NF4 linear needs in_features % 128 == 0 and out_features % 64 == 0, got {K}, {N}")
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.stride(0) * x2.element_size()) % 16 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    bias = None if base.bias is None else base.bias.data
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    y = _QLoRAThinFn.apply(x2, A, eb, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
+    return y.reshape(*x.shape[:-1], N)
+
+
 def qlora_linear(x, base: NF4Linear, ea, eb):
     """x: (..., K) device tensor (bf16 or f32). ea: (M, r_tot) or None, eb: (N, r_tot) or None."""
     if x.device.type != "cuda":
@@ -315,6 +432,9 @@ class LoRALinear(LoRALayer):
         if not self._lora_enabled():
             return self.linear(x)
         if isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD:
+            no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
+            if no_dropout and thin_route(x, self.linear):
+                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows() * self.scaling)
             ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
             return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
         pretrained = self.linear(x)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 2   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward */
+#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -199,6 +199,24 @@ int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const ui
 /*      dense dequantisation (merge path: lora.py:142-168 dequantize + add LoRA + requantize)     */
 int fastmax_hip_nf4_dequantize(const uint8_t* wq, const float* absmax, void* out, int64_t n, int dtype,
                                void* stream);
+
+/* ---- QLoRA linear at training sizes: the rank-r products around the library GEMM of the frozen weight
+ *      (csrc/lora_thin.hip).  Replaces the tensor ops of lit_gpt/lora.py:170-177 / :419-433 and their autograd mirror
+ *      when the base product runs as a dense GEMM.  All matrices bf16 row-major, leading dimensions in elements,
+ *      fp32 accumulation; RP = rank padded with zero columns to 16 or 32.
+ *        down: e[M][RP] = x[M][K] . bt[RP][K]^T;  et (or NULL) receives e^T as [RP][ldet], zero from column M to ldet
+ *              (ldet a multiple of 16, >= M).  K % 64 == 0, 16-byte aligned rows.                                  */
+int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
+                          int64_t ldet, int M, int K, int RP, void* stream);
+/*        tn:   out = et[R][M] . x[M][ncols], written as [R][ncols] (or [ncols][R] when `transpose`) in out_dtype
+ *              (FASTMAX_F32 / FASTMAX_BF16), fp32 sums in a fixed order;  et as written by lora_down (zero padded to a
+ *              multiple of 16 columns), R <= RP valid rows.  ncols % 64 == 0.  workspace: fastmax_hip_lora_tn_workspace bytes. */
+int64_t fastmax_hip_lora_tn_workspace(int M, int ncols, int RP);
+int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose,
+                        int R, void* workspace, int M, int ncols, int RP, void* stream);
+/*        up:   y[M][N] += e[M][R] . bn[N][R]^T (+ bias[N], float32 or NULL), in place.  R in {8,16,24,32}, N % 8 == 0. */
+int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, const float* bias,
+                        int M, int N, int R, void* stream);
 
 /* ---- introspection */
 int fastmax_hip_abi_version(void);

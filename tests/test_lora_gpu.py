@@ -176,3 +176,84 @@ def test_generation_size_rows_with_lora_branch_and_bias(M):
         y = layer(x)
     ref = _dense_reference(layer, x)
     assert y.shape == (M, N) and _rel(y, ref) < 1.5e-2
+
+
+# ---- rank-r kernels around the library GEMM (csrc/lora_thin.hip) -------------------------------------------------
+@pytest.mark.parametrize("M,K,N,R", [(2048, 256, 320, 16), (2049, 512, 128, 8), (4100, 256, 192, 24), (1, 128, 64, 32), (77, 1024, 2560, 16)])
+def test_lora_thin_kernels_against_tensor_ops(M, K, N, R):
+    """lora_down / lora_tn / lora_up_ against float32 tensor math on the same bf16 operands (ragged row counts, every rank
+    the layers can have, bias): down and up round once to bf16, tn sums in float32"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(M + R)
+    RP = 16 if R <= 16 else 32
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    dy = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+    A = torch.zeros(RP, K, device="cuda", dtype=torch.bfloat16)
+    A[:R] = torch.randn(R, K, device="cuda") * 0.1
+    e, et = lora.lora_down(x, A)
+    ref = x.float() @ A.float().t()
+    assert _rel(e, ref) < 8e-3
+    assert et.shape == (RP, (M + 15) // 16 * 16) and torch.equal(et[:, :M], e.t()) and not et[:, M:].any()
+    c = lora.lora_tn(et, dy)
+    refc = e.float().t() @ dy.float()
+    assert c.dtype == torch.float32 and _rel(c, refc) < 2e-5
+    ct = lora.lora_tn(et, dy, R, torch.bfloat16, transpose=True)
+    assert ct.shape == (N, R) and ct.dtype == torch.bfloat16 and _rel(ct, refc[:R].t()) < 8e-3
+    bn = torch.randn(N, R, device="cuda", dtype=torch.bfloat16) * 0.1
+    bias = torch.randn(N, device="cuda")
+    y0 = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+    er = e[:, :R].contiguous()
+    y = lora.lora_up_(y0.clone(), er, bn, bias)
+    assert _rel(y, y0.float() + er.float() @ bn.float().t() + bias) < 8e-3
+    y = lora.lora_up_(y0.clone(), er, bn)
+    assert _rel(y, y0.float() + er.float() @ bn.float().t()) < 8e-3
+
+
+@pytest.mark.parametrize("kind", ["linear", "qkv_gqa_qv", "qkv_gqa_all"])
+def test_many_rows_route_matches_the_tensor_op_route(kind, monkeypatch):
+    """M >= DENSE_M: the HIP rank-r route (_QLoRAThinFn) against the same layer with FASTMAX_LORA_THIN off (library GEMMs
+    for every product) and against the dense float32 formulation -- forward, dx, dA, dB"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(3)
+    if kind == "linear":
+        layer = lora.LoRALinear(256, 384, r=8, lora_alpha=16, bias=True)
+    elif kind == "qkv_gqa_qv":
+        layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=(True, False, True))
+    else:
+        layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda().to(torch.bfloat16)
+    lora.mark_only_lora_as_trainable(layer)
+    x = torch.randn(3, 700, 256, device="cuda", dtype=torch.bfloat16)
+    gy = None
+    res = []
+    for thin in (True, False):
+        monkeypatch.setattr(lora, "LORA_THIN", thin)
+        assert lora.thin_route(x, layer.linear) == thin
+        xx = x.clone().requires_grad_(True)
+        y = layer(xx)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        res.append((y.detach(), xx.grad, layer.lora_A.grad.clone(), layer.lora_B.grad.clone()))
+        layer.lora_A.grad = layer.lora_B.grad = None
+    for a, b in zip(*res):
+        assert a.dtype == b.dtype and _rel(a, b) < 2e-2
+    assert _rel(res[0][0], _dense_reference(layer, x)) < 2e-2
+
+
+def test_many_rows_route_is_skipped_under_dropout(monkeypatch):
+    """the rank-r route computes x A^T itself, so a layer with active LoRA dropout keeps the tensor-op branch"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(4)
+    layer = lora.LoRALinear(128, 128, r=8, lora_alpha=16, lora_dropout=0.5)
+    layer.quantize_base().cuda().to(torch.bfloat16)
+    called = []
+    monkeypatch.setattr(lora, "qlora_linear_thin", lambda *a, **k: called.append(1))
+    x = torch.randn(2048, 128, device="cuda", dtype=torch.bfloat16)
+    layer.train()
+    y = layer(x)
+    assert not called and y.shape == (2048, 128)
+    layer.eval()
+    layer(x)
+    assert called

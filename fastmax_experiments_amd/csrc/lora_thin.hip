@@ -11,8 +11,8 @@
 //         load instruction takes 64 contiguous bytes of 16 rows), cross-wave sum through LDS.
 //   tn  : the contraction runs down the rows of X, so 64-row x 64-column tiles are staged in an LDS image and read with
 //         ds_read_b64_tr_b16 (the same transposed fragment the fastmax state kernels use); workgroups own a 64-column slab
-//         and a range of rows, X tiles are fetched two stages ahead; per-range partials are summed (and cast / transposed)
-//         by a second small kernel in a fixed order.
+//         and a range of rows; X tiles and the matching E^T columns are fetched two stages ahead and staged one stage ahead;
+//         per-range partials are summed (and cast / transposed) by a second small kernel in a fixed order.
 //   up  : read-modify-write of Y with 16-byte accesses, lane = 8 (or 4) consecutive columns, wave = one row per step;
 //         the row's R coefficients are wave-uniform (one dword per lane + v_readlane), Bn lives in registers.  As many waves
 //         as the device holds at once, each walking its column slab with two row blocks in flight.
@@ -132,82 +132,76 @@ struct TnParams {
 
 template <int RPB, int KS>   // stages of 32 KS rows
 __global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * KS * 128];
+    constexpr int SR = 32 * KS, SB = SR * 128;                  // X stage: SR rows x 64 columns
+    constexpr int RSA = 2 * SR + 16, AB = 16 * RPB * RSA;       // E^T stage: 16 RPB rows x SR columns, padded rows
+    constexpr int NP8 = (RPB * KS + 1) / 2;                     // 8-byte pieces of the E^T stage per thread
+    __shared__ __attribute__((aligned(16))) char smem[2 * SB + 2 * AB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 64, s = blockIdx.y;
     const int mbeg = s * p.rps, mend = min(p.M, mbeg + p.rps);
-    constexpr int SR = 32 * KS, SB = SR * 128;
     const int nst = (mend - mbeg + SR - 1) / SR;
     f32x4 acc[RPB];
 #pragma unroll
     for (int cb = 0; cb < RPB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct XRegs { tu32x4 v[KS]; };
-    tu32x2 ar[RPB][KS][2];
-    // X tiles are fetched two stages ahead (two register sets), the small E^T fragments one stage ahead
-    auto fetch_x = [&](int st, XRegs& x) {
+    // both operands go global -> registers (two stages ahead) -> LDS (one stage ahead) -> fragments
+    struct Regs { tu32x4 x[KS]; tu32x2 a[NP8]; };
+    auto fetch = [&](int st, Regs& t) {
         const int mb = mbeg + st * SR;
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             const int piece = tid + 256 * i, row = piece >> 3, chunk = piece & 7;
-            x.v[i] = tu32x4{0, 0, 0, 0};
-            if (mb + row < mend) x.v[i] = THIN_STREAM_LOAD(reinterpret_cast<const tu32x4*>(p.x + (int64_t)(mb + row) * p.ldx + n0 + 8 * chunk));
+            t.x[i] = tu32x4{0, 0, 0, 0};
+            if (mb + row < mend) t.x[i] = THIN_STREAM_LOAD(reinterpret_cast<const tu32x4*>(p.x + (int64_t)(mb + row) * p.ldx + n0 + 8 * chunk));
+        }
+#pragma unroll
+        for (int i = 0; i < NP8; ++i) {
+            const int piece = tid + 256 * i, c = piece / (8 * KS), mm = mb + (piece % (8 * KS)) * 4;
+            t.a[i] = tu32x2{0, 0};
+            if (c < 16 * RPB && mm < mend && mm + 4 <= p.etcols) t.a[i] = *reinterpret_cast<const tu32x2*>(p.et + (int64_t)c * p.ldet + mm);
         }
     };
-    auto fetch_a = [&](int st) {
-        const int mb = mbeg + st * SR;
-#pragma unroll
-        for (int cb = 0; cb < RPB; ++cb)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int mm = mb + 32 * ks + 16 * h + 4 * q;      // the k order of ld_tr8: rows 4q+{0..3}, 16+4q+{0..3}
-                    ar[cb][ks][h] = tu32x2{0, 0};
-                    if (mm < mend && mm + 4 <= p.etcols) ar[cb][ks][h] = *reinterpret_cast<const tu32x2*>(p.et + (int64_t)(cb * 16 + r) * p.ldet + mm);
-                }
-    };
-    auto stage = [&](const XRegs& x, int buf) {
+    auto stage = [&](const Regs& t, int buf) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             const int piece = tid + 256 * i, row = piece >> 3, chunk = piece & 7;
-            *reinterpret_cast<tu32x4*>(smem + buf * SB + img_off<64>(row, chunk)) = x.v[i];
+            *reinterpret_cast<tu32x4*>(smem + buf * SB + img_off<64>(row, chunk)) = t.x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP8; ++i) {
+            const int piece = tid + 256 * i, c = piece / (8 * KS), mo = (piece % (8 * KS)) * 4;
+            if (c < 16 * RPB) *reinterpret_cast<tu32x2*>(smem + 2 * SB + buf * AB + c * RSA + mo * 2) = t.a[i];
         }
     };
-    auto step = [&](int st, const XRegs& xnext, XRegs& xfree) {
+    auto step = [&](int st, const Regs& next, Regs& free) {
         const int buf = st & 1;
-        tu32x2 a[RPB][KS][2];
-#pragma unroll
-        for (int cb = 0; cb < RPB; ++cb)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { a[cb][ks][0] = ar[cb][ks][0]; a[cb][ks][1] = ar[cb][ks][1]; }
-        if (st + 1 < nst) fetch_a(st + 1);
-        if (st + 2 < nst) fetch_x(st + 2, xfree);
+        if (st + 2 < nst) fetch(st + 2, free);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 b = ld_tr8<64>(smem, buf * SB, 32 * ks, 16 * wave, lane);
 #pragma unroll
             for (int cb = 0; cb < RPB; ++cb) {
+                // the k order of ld_tr8: rows 4q+{0..3}, then 16+4q+{0..3}
+                const char* ap = smem + 2 * SB + buf * AB + (cb * 16 + r) * RSA + (32 * ks + 4 * q) * 2;
                 union { bf16x8 v; tu32x2 h[2]; } u;
-                u.h[0] = a[cb][ks][0];
-                u.h[1] = a[cb][ks][1];
+                u.h[0] = *reinterpret_cast<const tu32x2*>(ap);
+                u.h[1] = *reinterpret_cast<const tu32x2*>(ap + 32);
                 acc[cb] = mfma(u.v, b, acc[cb]);
             }
         }
-        if (st + 1 < nst) stage(xnext, buf ^ 1);
+        if (st + 1 < nst) stage(next, buf ^ 1);
         __syncthreads();
     };
-    XRegs xa, xb;
+    Regs ra, rb;
     if (nst > 0) {
-        fetch_x(0, xa);
-        if (nst > 1) fetch_x(1, xb);
-        fetch_a(0);
-        stage(xa, 0);
+        fetch(0, ra);
+        if (nst > 1) fetch(1, rb);
+        stage(ra, 0);
     }
     __syncthreads();
     for (int st = 0; st < nst; st += 2) {
-        step(st, xb, xa);
-        if (st + 1 < nst) step(st + 1, xa, xb);
+        step(st, rb, ra);
+        if (st + 1 < nst) step(st + 1, ra, rb);
     }
     // C: column n = 16 wave + (lane & 15), row c = 16 cb + 4 q + i
     float* out = p.part + ((int64_t)s * RPB * 16) * p.ncols + n0 + 16 * wave + r;

@@ -89,8 +89,9 @@ class fastattention_einops(torch.autograd.Function):
         if Dp != D:
             qd, kd, vd = (torch.nn.functional.pad(t, (0, Dp - D)) for t in (qd, kd, vd))
         out_dt = _out_dtype(kdt, causal)
-        o, g = ops.forward(qd, kd, vd, p, causal, nt, g0=float(q.shape[2]), out_dtype=out_dt)
+        o, g, states = ops.forward(qd, kd, vd, p, causal, nt, g0=float(q.shape[2]), out_dtype=out_dt, keep_states=True)
         ctx.save_for_backward(qd, kd, vd, o, g)
+        ctx.states = states            # the forward's sequence-split prefix states (or None): the backward reuses them
         ctx.mask, ctx.normalize_term, ctx.p = mask, nt, p
         ctx.home, ctx.in_dtype, ctx.forward_only, ctx.D = home, in_dtype, False, D
         if Dp != D:
@@ -115,7 +116,7 @@ class fastattention_einops(torch.autograd.Function):
                                       ctx.normalize_term)
         else:
             dq, dk, dv = ops.backward(q, k, v, o, g, ops._prep(go.to(q.dtype), q.device), ctx.p, causal,
-                                      ctx.normalize_term)
+                                      ctx.normalize_term, states=ctx.states)
         if q.shape[-1] != ctx.D:
             dq, dk, dv = (t[..., :ctx.D].contiguous() for t in (dq, dk, dv))
         dq, dk, dv = (t.to(device=ctx.home, dtype=ctx.in_dtype) for t in (dq, dk, dv))

@@ -112,10 +112,22 @@ size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
     return a > b ? a : b;
 }
 
-int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+size_t fastmax_hip_forward_state_bytes(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                                       const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o) {
+    if (validate(prob) || !q || !k || !v || !o || !q_strides || !k_strides || !v_strides) return 0;
+    if (select(*prob) != FASTMAX_PATH_MFMA) return 0;
+    // the same layout rule as fastmax_hip_forward: anything else takes a kernel without a sequence split
+    if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) && aligned16(v, v_strides, prob->in_dtype) &&
+          !(reinterpret_cast<uintptr_t>(o) & 15)))
+        return 0;
+    if (split_plan(*prob).nseg <= 1) return 0;
+    return split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128);
+}
+
+int fastmax_hip_backward_with_states(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                          const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o,
                          const float* g, const void* grad_o, const int64_t* go_strides, void* dq, void* dk, void* dv,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         void* workspace, size_t workspace_bytes, const void* fwd_states, size_t fwd_state_bytes, void* stream) {
     int rc = validate(prob);
     if (rc) return rc;
     if (!q || !k || !v || !o || !g || !grad_o || !dq || !dk || !dv || !q_strides || !k_strides || !v_strides ||
@@ -123,6 +135,9 @@ int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64
         return FASTMAX_E_NULL;
     BwdArgs a{*prob, q, k, v, o, grad_o, g, st(q_strides), st(k_strides), st(v_strides), st(go_strides), dq, dk, dv,
               workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
+    if (fwd_states && fwd_state_bytes >= fastmax_hip_forward_state_bytes(prob, q, q_strides, k, k_strides, v, v_strides, o) && fwd_state_bytes > 0 &&
+        !(reinterpret_cast<uintptr_t>(fwd_states) & 15))
+        a.fwd_states = reinterpret_cast<const float*>(fwd_states);
     // matrix-core tiles unless the caller forces the vector-ALU family or the layout rules it out
     const bool mfma_ok = prob->path != FASTMAX_PATH_QUADRATIC && quad_mfma_bwd_supported(*prob) &&
                          aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
@@ -135,6 +150,14 @@ int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64
                      !(reinterpret_cast<uintptr_t>(o) & 15);
     if (lin) return launch_bwd_lin(a);
     return quad32_bwd_supported(*prob) ? launch_bwd_quad32(a) : launch_bwd_quad_mfma(a);
+}
+
+int fastmax_hip_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                         const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o,
+                         const float* g, const void* grad_o, const int64_t* go_strides, void* dq, void* dk, void* dv,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    return fastmax_hip_backward_with_states(prob, q, q_strides, k, k_strides, v, v_strides, o, g, grad_o, go_strides, dq, dk, dv, workspace,
+                                            workspace_bytes, nullptr, 0, stream);
 }
 
 size_t fastmax_hip_normalize_workspace(int B, int H) { return sizeof(unsigned int) * (size_t)B * H; }

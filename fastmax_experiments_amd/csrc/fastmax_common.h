@@ -94,6 +94,7 @@ struct BwdArgs {
     void* workspace;
     size_t workspace_bytes;
     hipStream_t stream;
+    const float* fwd_states = nullptr;   // the forward's sequence-split prefix states, when the caller kept them
 };
 
 int launch_fwd_quadratic(const FwdArgs& a);

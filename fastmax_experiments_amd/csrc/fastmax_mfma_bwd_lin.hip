@@ -573,16 +573,17 @@ int launch_bwd_lin(const BwdArgs& a) {
     char* ws = reinterpret_cast<char*>(a.workspace);
     float* cbuf = reinterpret_cast<float*>(ws);
     const size_t coff = align16(sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq), sbytes = align16(split_workspace_bytes(a.prob, dp));
-    float* fstate = reinterpret_cast<float*>(ws + coff);
+    // forward-scan states: the forward's own records when the caller kept its workspace, else recomputed below
+    const float* fstate = a.fwd_states ? a.fwd_states : reinterpret_cast<const float*>(ws + coff);
     float* rstate = reinterpret_cast<float*>(ws + coff + sbytes);
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                      cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
                      fstate, rstate, plan.nseg, plan.cps};
     const int BH = a.prob.B * a.prob.H;
-    if (plan.nseg > 1) {
+    if (plan.nseg > 1 && !a.fwd_states) {
         // forward-scan states (sum k v^T, sum k) exactly as the forward's; the reverse-scan states need c_i, which the dQ
         // kernel writes, so they are computed between the two main kernels
-        FwdArgs fa{a.prob, a.q, a.k, a.v, a.qs, a.ks, a.vs, nullptr, nullptr, fstate, sbytes, a.stream};
+        FwdArgs fa{a.prob, a.q, a.k, a.v, a.qs, a.ks, a.vs, nullptr, nullptr, ws + coff, sbytes, a.stream};
         const int rc = launch_split_states(fa, plan, dp, nullptr);
         if (rc) return rc;
     }

@@ -4,6 +4,7 @@ PyTorch is used for device memory, streams and autograd bookkeeping only; all ar
 the hot path runs in libfastmax_hip.so.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -63,8 +64,13 @@ def selected_path(q, k, p, causal, nt=1.0):
     return _lib.lib().fastmax_hip_select_path(ctypes.byref(prob))
 
 
-def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True):
-    """q,k,v: device tensors (B,H,N,D) of one dtype in {f32,bf16,f16}. -> (o, g)"""
+KEEP_STATES = os.environ.get("FASTMAX_KEEP_STATES", "1") != "0"
+
+
+def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True, keep_states=False):
+    """q,k,v: device tensors (B,H,N,D) of one dtype in {f32,bf16,f16}. -> (o, g), or (o, g, states) with ``keep_states``:
+    the sequence-split prefix states the p=1 masked forward left in its workspace (None when this call has none), for
+    ``backward(..., states=...)``"""
     L = _lib.lib()
     if p not in (1, 2):
         raise ValueError(f"p should be 1 or 2, got p={p}")
@@ -81,10 +87,16 @@ def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True):
                                    v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr() if need_g else None,
                                    wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
     _lib.check(rc, "fastmax_hip_forward")
+    if keep_states:
+        nb = 0
+        if KEEP_STATES and wsb is not None:
+            nb = L.fastmax_hip_forward_state_bytes(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                                   v.data_ptr(), _strides(v), o.data_ptr())
+        return o, g, (wsb if 0 < nb <= wsb.numel() else None)
     return o, g
 
 
-def backward(q, k, v, o, g, grad_o, p, causal, nt):
+def backward(q, k, v, o, g, grad_o, p, causal, nt, states=None):
     L = _lib.lib()
     dev = q.device
     prob = _problem(q, k, q.dtype, o.dtype, p, causal, nt, 0.0)
@@ -93,11 +105,13 @@ def backward(q, k, v, o, g, grad_o, p, causal, nt):
     dv = torch.empty(v.shape, dtype=q.dtype, device=dev)
     wsb, wsp = _ws(L.fastmax_hip_backward_workspace(ctypes.byref(prob)), dev)
     with torch.cuda.device(dev):
-        rc = L.fastmax_hip_backward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
-                                    v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr(), grad_o.data_ptr(),
-                                    _strides(grad_o), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), wsp,
-                                    wsb.numel() if wsb is not None else 0, _stream(dev))
-    _lib.check(rc, "fastmax_hip_backward")
+        rc = L.fastmax_hip_backward_with_states(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                                v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr(), grad_o.data_ptr(),
+                                                _strides(grad_o), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), wsp,
+                                                wsb.numel() if wsb is not None else 0,
+                                                None if states is None else states.data_ptr(),
+                                                0 if states is None else states.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_backward_with_states")
     return dq, dk, dv
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up */
+#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -93,6 +93,24 @@ int fastmax_hip_backward(const fastmax_problem* prob,
                          const void* grad_o, const int64_t* go_strides,
                          void* dq, void* dk, void* dv,
                          void* workspace, size_t workspace_bytes, void* stream);
+/*      The p=1 masked forward splits long sequences into segments and leaves the per-segment prefix states
+ *      (sum k v^T, sum k) at the start of its workspace; the backward needs the same records.  A caller that keeps
+ *      the forward's workspace alive hands it back here and the backward skips recomputing them:
+ *      forward_state_bytes = how many leading bytes of the forward workspace hold them for this call (0: this
+ *      problem / layout takes a kernel without a split -- pass NULL).                                            */
+size_t fastmax_hip_forward_state_bytes(const fastmax_problem* prob,
+                                       const void* q, const int64_t* q_strides,
+                                       const void* k, const int64_t* k_strides,
+                                       const void* v, const int64_t* v_strides, const void* o);
+int fastmax_hip_backward_with_states(const fastmax_problem* prob,
+                                     const void* q, const int64_t* q_strides,
+                                     const void* k, const int64_t* k_strides,
+                                     const void* v, const int64_t* v_strides,
+                                     const void* o, const float* g,
+                                     const void* grad_o, const int64_t* go_strides,
+                                     void* dq, void* dk, void* dv,
+                                     void* workspace, size_t workspace_bytes,
+                                     const void* fwd_states, size_t fwd_state_bytes, void* stream);
 
 /* ---- linearmax prologue: replaces fastattention_einops.normalize (fastmax.py:326-334)
  *      == the inline copy at fastmax_hack.py:38-43 / 10-15: per token subtract the mean

@@ -691,3 +691,31 @@ def test_strided_views_give_the_same_bits_as_contiguous_tensors(p, mask, dt):
         outs.append([o.detach(), q.grad, k.grad, v.grad])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,dt", [((1, 4, 2048, 64), torch.bfloat16), ((2, 2, 1536, 64), torch.float32),
+                                      ((1, 3, 2048, 32), torch.float16), ((1, 2, 2048, 128), torch.bfloat16),
+                                      ((8, 64, 512, 64), torch.bfloat16)])
+def test_backward_reuses_the_forward_prefix_states(shape, dt):
+    """fastmax_hip_backward_with_states: handing the forward's sequence-split states back gives bit-identical gradients to
+    recomputing them; problems / layouts without a split report 0 state bytes and take the plain route"""
+    from fastmax_experiments_amd import ops
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(shape, device="cuda").to(dt) * 0.5 for _ in range(3))
+    go = torch.randn(shape, device="cuda").to(dt)
+    o, g, states = ops.forward(q, k, v, 1, True, 1.0, 0.0, dt, keep_states=True)
+    many_heads = shape[0] * shape[1] >= 512
+    assert (states is None) == many_heads                 # enough heads to fill the chip: no split, nothing to keep
+    o2, g2 = ops.forward(q, k, v, 1, True, 1.0, 0.0, dt)
+    assert torch.equal(o, o2) and torch.equal(g, g2)
+    ref = ops.backward(q, k, v, o, g, go, 1, True, 1.0)
+    got = ops.backward(q, k, v, o, g, go, 1, True, 1.0, states=states)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    if states is not None:
+        # a buffer that is too small, or states for a layout the forward would not have split, are ignored
+        small = states[: states.numel() // 2]
+        for a, b in zip(ops.backward(q, k, v, o, g, go, 1, True, 1.0, states=small), ref):
+            assert torch.equal(a, b)
+        # p = 2 has no carried state: nothing is kept
+        assert ops.forward(q, k, v, 2, True, 1.0, 0.0, dt, keep_states=True)[2] is None

@@ -257,8 +257,9 @@ static void tn_plan(int M, int ncols, int& S, int& rps) {
 struct UpParams {
     __bf16* y; int64_t ldy;
     const __bf16* e; int64_t lde;
-    const __bf16* bn; int64_t ldb;
+    const __bf16* bn; int64_t ldb;  // (N, R) rows, or (R, N) when bn_t
     const float* bias;             // may be null
+    int bn_t;
     int M, N, nslab, groups;       // groups: waves per column slab
 };
 
@@ -287,15 +288,28 @@ __global__ __launch_bounds__(256) void lora_up_kernel(const UpParams p) {
     const int nblk = (p.M + RU - 1) / RU;
     float b[NPL][R], bias[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        bias[j] = p.bias ? p.bias[nn + j] : 0.f;
+    for (int j = 0; j < NPL; ++j) bias[j] = p.bias ? p.bias[nn + j] : 0.f;
+    if (p.bn_t) {                                                            // (R, N): NPL consecutive columns of row c
 #pragma unroll
-        for (int c = 0; c < R; c += 8) {
-            const tu32x4 wv = *reinterpret_cast<const tu32x4*>(p.bn + (int64_t)(nn + j) * p.ldb + c);
+        for (int c = 0; c < R; ++c) {
+            const vec_t wv = *reinterpret_cast<const vec_t*>(p.bn + (int64_t)c * p.ldb + nn);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                b[j][c + 2 * t] = bf_lo(wv[t]);
-                b[j][c + 2 * t + 1] = bf_hi(wv[t]);
+            for (int j = 0; j < NPL; j += 2) {
+                b[j][c] = bf_lo(wv[j >> 1]);
+                b[j + 1][c] = bf_hi(wv[j >> 1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+#pragma unroll
+            for (int c = 0; c < R; c += 8) {
+                const tu32x4 wv = *reinterpret_cast<const tu32x4*>(p.bn + (int64_t)(nn + j) * p.ldb + c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    b[j][c + 2 * t] = bf_lo(wv[t]);
+                    b[j][c + 2 * t + 1] = bf_hi(wv[t]);
+                }
             }
         }
     }
@@ -368,6 +382,35 @@ template <int R, int NPL, int RU> static int up_launch(UpParams p, hipStream_t s
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the (RP, N) operand of the LoRA branch from lora_B: E^T[part r + j][n] = scaling B[row(part, n)][j], zero where the
+// output column n has no row in that part (LoRAQKVLinear's zero_pad / lora_ind scatter, lit_gpt/lora.py:263-342) and in
+// the padding rows; and the gather back for the gradient of lora_B
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename TB>
+__global__ __launch_bounds__(256) void lora_scatter_kernel(const TB* b, int r, const int* rowmap, int n_parts, float scaling, __bf16* et,
+                                                           int64_t ldet, int N, int RP) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)RP * N) return;
+    const int c = (int)(i / N), n = (int)(i % N);
+    const int part = c / r, j = c % r;
+    float v = 0.f;
+    if (part < n_parts) {
+        const int row = rowmap[(int64_t)part * N + n];
+        if (row >= 0) v = scaling * to_float(b[(int64_t)row * r + j]);
+    }
+    et[(int64_t)c * ldet + n] = (__bf16)v;
+}
+
+template <typename TB, typename TG>
+__global__ __launch_bounds__(256) void lora_scatter_bwd_kernel(const TG* d_et, int64_t ldd, const int* ind, const int* part, float scaling, TB* db,
+                                                               int n_rows, int r) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_rows * r) return;
+    const int row = (int)(i / r), j = (int)(i % r);
+    db[i] = from_float<TB>(scaling * to_float(d_et[(int64_t)(part[row] * r + j) * ldd + ind[row]]));
+}
+
 static bool aligned16(const void* ptr, int64_t ld_elems) { return !(reinterpret_cast<uintptr_t>(ptr) & 15) && (ld_elems * 2) % 16 == 0; }
 
 }  // namespace fastmax
@@ -428,12 +471,12 @@ int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx
     return (int)hipGetLastError();
 }
 
-int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, const float* bias, int M,
-                        int N, int R, void* stream) {
+int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                        const float* bias, int M, int N, int R, void* stream) {
     if (!y || !e || !bn) return FASTMAX_E_NULL;
-    if (M <= 0 || N <= 0 || N % 8 || ldy < N || lde < R || ldb < R) return FASTMAX_E_BAD_SHAPE;
+    if (M <= 0 || N <= 0 || N % 8 || ldy < N || lde < R || ldb < (bn_transposed ? N : R)) return FASTMAX_E_BAD_SHAPE;
     if (!aligned16(y, ldy) || !aligned16(e, lde) || !aligned16(bn, ldb)) return FASTMAX_E_BAD_SHAPE;
-    UpParams p{reinterpret_cast<__bf16*>(y), ldy, reinterpret_cast<const __bf16*>(e), lde, reinterpret_cast<const __bf16*>(bn), ldb, bias, M, N, 0, 0};
+    UpParams p{reinterpret_cast<__bf16*>(y), ldy, reinterpret_cast<const __bf16*>(e), lde, reinterpret_cast<const __bf16*>(bn), ldb, bias, bn_transposed ? 1 : 0, M, N, 0, 0};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const int variant = env_int("FASTMAX_LORA_UP_VARIANT", 0);
     switch (R) {
@@ -449,6 +492,42 @@ int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const 
         case 32: return up_launch<32, 4, 4>(p, s);
     }
     return FASTMAX_E_BAD_SHAPE;
+}
+
+int fastmax_hip_lora_scatter(const void* b, int b_dtype, int r, const int32_t* rowmap, int n_parts, float scaling, void* et,
+                             int64_t ldet, int N, int RP, void* stream) {
+    if (!b || !rowmap || !et) return FASTMAX_E_NULL;
+    if (r <= 0 || n_parts <= 0 || n_parts * r > RP || N <= 0 || ldet < N) return FASTMAX_E_BAD_SHAPE;
+    const int64_t n = (int64_t)RP * N;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (b_dtype == FASTMAX_F32)
+        hipLaunchKernelGGL((lora_scatter_kernel<float>), grid, dim3(256), 0, s, reinterpret_cast<const float*>(b), r, rowmap, n_parts, scaling,
+                           reinterpret_cast<__bf16*>(et), ldet, N, RP);
+    else if (b_dtype == FASTMAX_BF16)
+        hipLaunchKernelGGL((lora_scatter_kernel<bf16_t>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t*>(b), r, rowmap, n_parts, scaling,
+                           reinterpret_cast<__bf16*>(et), ldet, N, RP);
+    else return FASTMAX_E_BAD_DTYPE;
+    return (int)hipGetLastError();
+}
+
+int fastmax_hip_lora_scatter_backward(const void* d_et, int d_dtype, int64_t ldd, const int32_t* ind, const int32_t* part, float scaling,
+                                      void* db, int b_dtype, int n_rows, int r, void* stream) {
+    if (!d_et || !ind || !part || !db) return FASTMAX_E_NULL;
+    if (n_rows <= 0 || r <= 0) return FASTMAX_E_BAD_SHAPE;
+    const int64_t n = (int64_t)n_rows * r;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define SCATTER_BWD(TB, TG)                                                                                                       \
+    hipLaunchKernelGGL((lora_scatter_bwd_kernel<TB, TG>), grid, dim3(256), 0, s, reinterpret_cast<const TG*>(d_et), ldd, ind, part, scaling, \
+                       reinterpret_cast<TB*>(db), n_rows, r)
+    if (b_dtype == FASTMAX_F32 && d_dtype == FASTMAX_F32) SCATTER_BWD(float, float);
+    else if (b_dtype == FASTMAX_F32 && d_dtype == FASTMAX_BF16) SCATTER_BWD(float, bf16_t);
+    else if (b_dtype == FASTMAX_BF16 && d_dtype == FASTMAX_F32) SCATTER_BWD(bf16_t, float);
+    else if (b_dtype == FASTMAX_BF16 && d_dtype == FASTMAX_BF16) SCATTER_BWD(bf16_t, bf16_t);
+    else return FASTMAX_E_BAD_DTYPE;
+#undef SCATTER_BWD
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -266,14 +266,51 @@ def lora_tn(et: torch.Tensor, x: torch.Tensor, R: int = None, dtype=torch.float3
     return out if dtype == kdt else out.to(dtype)
 
 
-def lora_up_(y: torch.Tensor, e: torch.Tensor, bn: torch.Tensor, bias=None) -> torch.Tensor:
-    """y (M, N) += e (M, R) bn (N, R)^T (+ bias), in place; bf16, bias float32."""
+def lora_up_(y: torch.Tensor, e: torch.Tensor, bn: torch.Tensor, bias=None, transposed: bool = False) -> torch.Tensor:
+    """y (M, N) += e (M, R) bn^T (+ bias), in place; bn is (N, R), or (R, N) with ``transposed``; bf16, bias float32."""
     M, N = y.shape
     with torch.cuda.device(y.device):
         rc = _lib.lib().fastmax_hip_lora_up(y.data_ptr(), y.stride(0), e.data_ptr(), e.stride(0), bn.data_ptr(), bn.stride(0),
-                                            None if bias is None else bias.data_ptr(), M, N, e.shape[1], _stream(y.device))
+                                            int(transposed), None if bias is None else bias.data_ptr(), M, N, e.shape[1],
+                                            _stream(y.device))
     _lib.check(rc, "fastmax_hip_lora_up")
     return y
+
+
+_KDT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+class _ScatterRowsFn(torch.autograd.Function):
+    """lora_B (n_rows, r) -> the (RP, N) bf16 operand  E^T[part r + j][n] = scaling B[row(part, n)][j]  of the LoRA branch
+    (LoRAQKVLinear: the lora_ind / zero_pad scatter of lit_gpt/lora.py:263-342; LoRALinear: one part, identity map), one HIP
+    launch each way instead of zeros + index_put + mul (+ transpose copies)."""
+
+    @staticmethod
+    def forward(ctx, B, rowmap, ind, part, scaling, N, RP):
+        Bc = B.detach().contiguous()
+        et = torch.empty((RP, N), dtype=torch.bfloat16, device=B.device)
+        with torch.cuda.device(B.device):
+            rc = _lib.lib().fastmax_hip_lora_scatter(Bc.data_ptr(), _KDT[Bc.dtype], Bc.shape[1], rowmap.data_ptr(), rowmap.shape[0],
+                                                     float(scaling), et.data_ptr(), N, N, RP, _stream(B.device))
+        _lib.check(rc, "fastmax_hip_lora_scatter")
+        ctx.save_for_backward(ind, part)
+        ctx.meta = (Bc.shape, Bc.dtype, float(scaling))
+        return et
+
+    @staticmethod
+    def backward(ctx, d_et):
+        ind, part = ctx.saved_tensors
+        shape, dt, scaling = ctx.meta
+        if d_et.dtype not in _KDT:
+            d_et = d_et.float()
+        d_et = d_et.contiguous()
+        dB = torch.empty(shape, dtype=dt, device=d_et.device)
+        with torch.cuda.device(d_et.device):
+            rc = _lib.lib().fastmax_hip_lora_scatter_backward(d_et.data_ptr(), _KDT[d_et.dtype], d_et.stride(0), ind.data_ptr(),
+                                                              part.data_ptr(), scaling, dB.data_ptr(), _KDT[dt], shape[0], shape[1],
+                                                              _stream(d_et.device))
+        _lib.check(rc, "fastmax_hip_lora_scatter_backward")
+        return dB, None, None, None, None, None, None
 
 
 class _QLoRAThinFn(torch.autograd.Function):
@@ -282,40 +319,37 @@ class _QLoRAThinFn(torch.autograd.Function):
     one streaming pass each (lit_gpt/lora.py:170-177, 419-433 and their autograd mirror, without dropout)."""
 
     @staticmethod
-    def forward(ctx, x2, A, eb, wq, absmax, bias, N, K, wdense):
-        R = A.shape[0]
-        RP = _pad_rank(R)
-        if R == RP:                                   # no padding needed: use the operands as they are
-            abt, ebp = A.to(torch.bfloat16).contiguous(), eb.to(torch.bfloat16).contiguous()
+    def forward(ctx, x2, A, ebt, wq, absmax, bias, N, K, wdense):
+        R, RP = A.shape[0], ebt.shape[0]
+        if R == RP:                                   # no padding needed: use A as it is
+            abt = A.detach().to(torch.bfloat16).contiguous()
         else:
             abt = torch.zeros((RP, K), dtype=torch.bfloat16, device=x2.device)
-            abt[:R] = A
-            ebp = torch.zeros((N, RP), dtype=torch.bfloat16, device=x2.device)
-            ebp[:, :R] = eb
+            abt[:R] = A.detach()
         y = x2 @ (wdense if wdense is not None else _dense_weight(wq, absmax, N, K)).t()
         ea, eat = lora_down(x2, abt)
-        lora_up_(y, ea, ebp, bias)
-        ctx.save_for_backward(x2, eat, abt, ebp, wq, absmax)
+        lora_up_(y, ea, ebt, bias, transposed=True)
+        ctx.save_for_backward(x2, eat, abt, ebt, wq, absmax)
         ctx.wdense = wdense
-        ctx.dims = (N, K, R, A.dtype, eb.dtype)
+        ctx.dims = (N, K, R, A.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, eat, abt, ebp, wq, absmax = ctx.saved_tensors
-        N, K, R, a_dt, eb_dt = ctx.dims
+        x2, eat, abt, ebt, wq, absmax = ctx.saved_tensors
+        N, K, R, a_dt = ctx.dims
         dy = dy.contiguous()
-        dx = dA = d_eb = None
+        dx = dA = d_ebt = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            d_ea, d_eat = lora_down(dy, ebp.t().contiguous())
+            d_ea, d_eat = lora_down(dy, ebt)
         if ctx.needs_input_grad[0]:
             dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, absmax, N, K))
-            lora_up_(dx, d_ea, abt.t().contiguous())
+            lora_up_(dx, d_ea, abt, transposed=True)
         if ctx.needs_input_grad[1]:
             dA = lora_tn(d_eat, x2, R, a_dt)
         if ctx.needs_input_grad[2]:
-            d_eb = lora_tn(eat, dy, R, eb_dt, transpose=True)
-        return dx, dA, d_eb, None, None, None, None, None, None
+            d_ebt = lora_tn(eat, dy, dtype=torch.bfloat16)
+        return dx, dA, d_ebt, None, None, None, None, None, None
 
 
 def thin_route(x: torch.Tensor, base: "NF4Linear") -> bool:
@@ -326,8 +360,8 @@ def thin_route(x: torch.Tensor, base: "NF4Linear") -> bool:
     return M >= DENSE_M or base._dense_cache is not None
 
 
-def qlora_linear_thin(x, base: "NF4Linear", A, eb):
-    """x: (..., K) bf16 device tensor; A: (r, K); eb: (N, r) with the scaling applied."""
+def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
+    """x: (..., K) bf16 device tensor; A: (r, K); ebt: (RP, N) bf16 operand of the branch (scaling applied, rank zero padded)."""
     N, K = base.out_features, base.in_features
     if K % 128 or N % 64:
         raise NotImplementedError(f"fused NF4 linear needs in_features % 128 == 0 and out_features % 64 == 0, got {K}, {N}")
@@ -337,7 +371,7 @@ def qlora_linear_thin(x, base: "NF4Linear", A, eb):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRAThinFn.apply(x2, A, eb, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
+    y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -411,6 +445,22 @@ class LoRALinear(LoRALayer):
         """(out_features, r_total) matrix E with  lora(x) = (dropout(x) A^T) E^T * scaling."""
         return self.lora_B
 
+    def _scatter_maps(self):
+        """(rowmap (n_parts, N), ind (n_rows,), part (n_rows,)) int32: which lora_B row feeds output column n in each rank block"""
+        N = self.linear.out_features
+        ind = torch.arange(N, dtype=torch.int32)
+        return ind[None, :].clone(), ind, torch.zeros(N, dtype=torch.int32)
+
+    def _dense_rows_t(self) -> torch.Tensor:
+        """(RP, out_features) bf16: scaling * _dense_rows()^T with the rank zero padded to 16 / 32 -- one HIP launch"""
+        dev = self.lora_B.device
+        maps = getattr(self, "_maps_cache", None)
+        if maps is None or maps[0].device != dev:
+            maps = tuple(t.to(dev).contiguous() for t in self._scatter_maps())
+            self._maps_cache = maps
+        return _ScatterRowsFn.apply(self.lora_B, maps[0], maps[1], maps[2], self.scaling, self.linear.out_features,
+                                    _pad_rank(self.lora_A.shape[0]))
+
     def merge(self) -> None:
         """W <- W + dW (lora.py:142-168); the 4-bit branch dequantises, adds and requantises."""
         if self.r > 0 and not self.merged:
@@ -434,7 +484,7 @@ class LoRALinear(LoRALayer):
         if isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD:
             no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
             if no_dropout and thin_route(x, self.linear):
-                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows() * self.scaling)
+                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t())
             ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
             return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
         pretrained = self.linear(x)
@@ -512,6 +562,15 @@ class LoRAQKVLinear(LoRALinear):
         ind = torch.arange(self.linear.out_features, device=E.device) if all(self.enable_lora) else self._ind.to(E.device)
         rows = ind[:, None].expand(-1, self.r)
         return E.index_put((rows, self._cols.to(E.device)), self.lora_B)
+
+    def _scatter_maps(self):
+        N = self.linear.out_features
+        # rows sit at their own index when all three parts are enabled (the zero_pad identity quirk, see _dense_rows)
+        ind = torch.arange(N) if all(self.enable_lora) else self._ind.cpu()
+        part = (self._cols[:, 0] // self.r).cpu()
+        rowmap = torch.full((len(self.qkv_shapes), N), -1, dtype=torch.int32)
+        rowmap[part, ind] = torch.arange(ind.numel(), dtype=torch.int32)
+        return rowmap, ind.to(torch.int32), part.to(torch.int32)
 
     def merge(self) -> None:
         if self.r > 0 and any(self.enable_lora) and not self.merged:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -232,9 +232,18 @@ int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ld
 int64_t fastmax_hip_lora_tn_workspace(int M, int ncols, int RP);
 int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose,
                         int R, void* workspace, int M, int ncols, int RP, void* stream);
-/*        up:   y[M][N] += e[M][R] . bn[N][R]^T (+ bias[N], float32 or NULL), in place.  R in {8,16,24,32}, N % 8 == 0. */
-int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, const float* bias,
-                        int M, int N, int R, void* stream);
+/*        up:   y[M][N] += e[M][R] . bn[N][R]^T (+ bias[N], float32 or NULL), in place; bn as (N, R) rows, or as (R, N)
+ *              rows when bn_transposed.  R in {8,16,24,32}, N % 8 == 0.                                                */
+int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                        const float* bias, int M, int N, int R, void* stream);
+/*        scatter: the (RP, N) bf16 operand of the branch from lora_B (n_rows, r; b_dtype F32 / BF16):
+ *              et[part r + j][n] = scaling b[rowmap[part][n]][j], 0 where rowmap is -1 and in rows >= n_parts r
+ *              (LoRAQKVLinear's lora_ind / zero_pad, lit_gpt/lora.py:263-342; one part with the identity map = LoRALinear).
+ *              backward: db[i][j] = scaling d_et[part[i] r + j][ind[i]]  (d_dtype F32 / BF16).                          */
+int fastmax_hip_lora_scatter(const void* b, int b_dtype, int r, const int32_t* rowmap, int n_parts, float scaling, void* et,
+                             int64_t ldet, int N, int RP, void* stream);
+int fastmax_hip_lora_scatter_backward(const void* d_et, int d_dtype, int64_t ldd, const int32_t* ind, const int32_t* part,
+                                      float scaling, void* db, int b_dtype, int n_rows, int r, void* stream);
 
 /* ---- introspection */
 int fastmax_hip_abi_version(void);

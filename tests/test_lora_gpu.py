@@ -257,3 +257,44 @@ def test_many_rows_route_is_skipped_under_dropout(monkeypatch):
     layer.eval()
     layer(x)
     assert called
+
+
+@pytest.mark.parametrize("kind", ["linear", "qkv_gqa_qv", "qkv_gqa_all", "qkv_k_only"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_scattered_operand_matches_dense_rows(kind, dt):
+    """_dense_rows_t (one HIP launch) == (scaling * _dense_rows())^T zero padded to the kernel rank, and its backward is the
+    gather of the same entries -- against autograd through the tensor-op formulation"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(7)
+    if kind == "linear":
+        layer = lora.LoRALinear(128, 192, r=8, lora_alpha=16)
+    else:
+        en = {"qkv_gqa_qv": (True, False, True), "qkv_gqa_all": True, "qkv_k_only": (False, True, False)}[kind]
+        layer = lora.LoRAQKVLinear(128, (8 + 4) * 16, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=en)
+    torch.nn.init.normal_(layer.lora_B)
+    layer.cuda().to(dt)
+    et = layer._dense_rows_t()
+    R = layer.lora_A.shape[0]
+    RP = 16 if R <= 16 else 32
+    ref = (layer._dense_rows().float() * layer.scaling).t()
+    assert et.shape == (RP, layer.linear.out_features) and et.dtype == torch.bfloat16
+    assert torch.equal(et[:R], ref.to(dt).to(torch.bfloat16) if dt == torch.bfloat16 else ref.to(torch.bfloat16)) or _rel(et[:R], ref) < 4e-3
+    assert not et[R:].any()
+    w = torch.randn_like(et)
+    (et.float() * w.float()).sum().backward()
+    got = layer.lora_B.grad.clone()
+    layer.lora_B.grad = None
+    ((layer._dense_rows().float() * layer.scaling).t() * w[:R].float()).sum().backward()
+    assert got.dtype == dt and _rel(got, layer.lora_B.grad) < (1e-6 if dt == torch.float32 else 8e-3)
+
+
+def test_lora_up_transposed_operand():
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(8)
+    M, N, R = 300, 320, 16
+    y0 = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+    e = torch.randn(M, R, device="cuda", dtype=torch.bfloat16)
+    bn = torch.randn(N, R, device="cuda", dtype=torch.bfloat16) * 0.1
+    a = lora.lora_up_(y0.clone(), e, bn)
+    b = lora.lora_up_(y0.clone(), e, bn.t().contiguous(), transposed=True)
+    assert torch.equal(a, b)

@@ -188,9 +188,18 @@ int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtyp
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
     if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
     if (D * es > 512) return FASTMAX_E_BAD_SHAPE;
-    int rc = launch_normalize_stats(x, st(x_strides), dtype, inv_norm, B, H, N, D, workspace, reinterpret_cast<hipStream_t>(stream));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int npart = (N + 255) / 256;
+    if (workspace_bytes >= sizeof(unsigned int) * (size_t)B * H * npart) {
+        // two launches: per-block maxima, then the row pass combines them (no zeroing pass, no atomics, no finish pass)
+        unsigned int* partials = reinterpret_cast<unsigned int*>(workspace);
+        int rc = launch_normalize_partial_max(x, st(x_strides), dtype, partials, B, H, N, D, s);
+        if (rc) return rc;
+        return launch_normalize_cast(x, st(x_strides), dtype, y, nullptr, B, H, N, D, s, partials, npart, inv_norm);
+    }
+    int rc = launch_normalize_stats(x, st(x_strides), dtype, inv_norm, B, H, N, D, workspace, s);
     if (rc) return rc;
-    return launch_normalize_cast(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, reinterpret_cast<hipStream_t>(stream));
+    return launch_normalize_cast(x, st(x_strides), dtype, y, inv_norm, B, H, N, D, s);
 }
 
 size_t fastmax_hip_normalize_backward_workspace(int B, int H, int N) { return normalize_backward_workspace(B, H, N); }

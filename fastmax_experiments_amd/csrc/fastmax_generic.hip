@@ -486,7 +486,7 @@ int launch_bwd_quadratic(const BwdArgs& a) {
 // the head's word).  Rows must be 16-byte aligned; `vec` = 0 selects the scalar-load form for unaligned views.
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_max_kernel(const void* x, Strides3 xs, int H, int N, int D,
-                                                            unsigned int* maxbits, int vec) {
+                                                            unsigned int* maxbits, int vec, int partial) {
     constexpr int TOK = 256, EPL = 16 / sizeof(T), RPB = 256 / LPR;
     __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -528,7 +528,12 @@ __global__ __launch_bounds__(256) void normalize_max_kernel(const void* x, Strid
     if (lane == 0) wmax[wave] = best;
     __syncthreads();
     // squared norms are >= 0, so their float bit patterns order like unsigned integers
-    if (tid == 0) atomicMax(&maxbits[bh], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    if (tid == 0) {
+        const unsigned int bits = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+        // partial: one word per block, combined by the consumer (no zeroing pass, no atomics); else one word per head
+        if (partial) maxbits[(int64_t)bh * gridDim.x + blockIdx.x] = bits;
+        else atomicMax(&maxbits[bh], bits);
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void normalize_apply_kernel(const void* x, Strides3 xs, int H, int N, int D,
@@ -557,14 +562,14 @@ static int rows_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
 
 // lanes per token row: the smallest power of two that covers D with 16-byte pieces (4..32)
 template <typename T>
-static void launch_max_lpr(const void* x, Strides3 xs, int B, int H, int N, int D, unsigned int* maxbits, hipStream_t stream) {
+static void launch_max_lpr(const void* x, Strides3 xs, int B, int H, int N, int D, unsigned int* maxbits, hipStream_t stream, int partial = 0) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
     const int vec = rows_vec_ok(x, xs, sizeof(T), D);
     dim3 grid((N + 255) / 256, B * H), block(256);                 // TOK = 256 tokens per block
-    if (need <= 4) hipLaunchKernelGGL((normalize_max_kernel<T, 4>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
-    else if (need <= 8) hipLaunchKernelGGL((normalize_max_kernel<T, 8>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
-    else if (need <= 16) hipLaunchKernelGGL((normalize_max_kernel<T, 16>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
-    else hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec);
+    if (need <= 4) hipLaunchKernelGGL((normalize_max_kernel<T, 4>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
+    else if (need <= 8) hipLaunchKernelGGL((normalize_max_kernel<T, 8>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
+    else if (need <= 16) hipLaunchKernelGGL((normalize_max_kernel<T, 16>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
+    else hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
 }
 
 // zero the per-head max words with a kernel, not hipMemsetAsync: a memset node inside a captured HIP graph was observed
@@ -603,6 +608,18 @@ static int launch_stats_t(const void* x, Strides3 xs, float* inv_norm, int B, in
     hipLaunchKernelGGL(normalize_finish_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, maxbits, inv_norm, B * H);
     return (int)hipGetLastError();
 }
+// per-block maxima of the squared centred norm: partials[bh][ceil(N / 256)] (float bit patterns), no zeroing, no atomics
+int launch_normalize_partial_max(const void* x, Strides3 xs, int dtype, unsigned int* partials, int B, int H, int N, int D,
+                                 hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: launch_max_lpr<float>(x, xs, B, H, N, D, partials, stream, 1); break;
+        case FASTMAX_BF16: launch_max_lpr<bf16_t>(x, xs, B, H, N, D, partials, stream, 1); break;
+        case FASTMAX_F16: launch_max_lpr<f16_t>(x, xs, B, H, N, D, partials, stream, 1); break;
+        default: return FASTMAX_E_BAD_DTYPE;
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
                            void* workspace, hipStream_t stream) {
     switch (dtype) {

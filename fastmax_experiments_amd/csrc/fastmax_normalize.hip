@@ -59,11 +59,21 @@ template <int LPR> __device__ __forceinline__ float group_sum(float s) {
 // ---- forward: y (dtype T, contiguous) = (x - mean) * inv[bh];  grid = (ceil(N / (256/LPR) / RPT), B*H) -----------------
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_cast_kernel(const void* x, Strides3 xs, int H, int N, int D, const float* inv_norm,
-                                                             T* y, int vec) {
+                                                             T* y, int vec, const unsigned int* partials, int npart, float* inv_out) {
     constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
     const int tid = threadIdx.x, sub = tid % LPR, rgrp = tid / LPR;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    float inv;
+    if (partials) {
+        // the head's maximum from the per-block words of normalize_max_kernel (same fmaxf chain as the atomic form)
+        float m = 0.f;
+        for (int i = 0; i < npart; ++i) m = fmaxf(m, __uint_as_float(partials[(int64_t)bh * npart + i]));
+        inv = 1.0f / sqrtf(m);
+        if (blockIdx.x == 0 && tid == 0) inv_out[bh] = inv;
+    } else {
+        inv = inv_norm[bh];
+    }
+    const float invD = 1.0f / (float)D;
     const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         float v[EPL];
@@ -186,23 +196,26 @@ static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
     else { CALL(32); }
 
 template <typename T>
-static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream) {
+static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream,
+                            const unsigned int* partials, int npart, float* inv_out) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
     if (need > 32) return FASTMAX_E_BAD_SHAPE;
     // 16-byte accesses need whole pieces per row and aligned rows on both sides; otherwise element-wise loads / stores
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(y) & 15);
     const dim3 grid((N + 255) / 256, B * H), block(256);
-#define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec)
+#define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec, partials, npart, inv_out)
     NRM_LPR_SWITCH(need, CALL)
 #undef CALL
     return (int)hipGetLastError();
 }
+// partials == nullptr: inv_norm is an input.  Else inv_norm is computed from the npart per-block maxima of each head
+// (launch_normalize_partial_max) and written to inv_out
 int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const float* inv_norm, int B, int H, int N, int D,
-                          hipStream_t stream) {
+                          hipStream_t stream, const unsigned int* partials, int npart, float* inv_out) {
     switch (dtype) {
-        case FASTMAX_F32: return normalize_cast_t<float>(x, xs, y, inv_norm, B, H, N, D, stream);
-        case FASTMAX_BF16: return normalize_cast_t<bf16_t>(x, xs, y, inv_norm, B, H, N, D, stream);
-        case FASTMAX_F16: return normalize_cast_t<f16_t>(x, xs, y, inv_norm, B, H, N, D, stream);
+        case FASTMAX_F32: return normalize_cast_t<float>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
+        case FASTMAX_BF16: return normalize_cast_t<bf16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
+        case FASTMAX_F16: return normalize_cast_t<f16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
     }
     return FASTMAX_E_BAD_DTYPE;
 }

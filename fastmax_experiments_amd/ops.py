@@ -140,7 +140,8 @@ def normalize_cast(x):
     B, H, N, D = x.shape
     y = torch.empty((B, H, N, D), dtype=x.dtype, device=dev)
     inv = torch.empty((B, H), dtype=torch.float32, device=dev)
-    wsb, wsp = _ws(L.fastmax_hip_normalize_workspace(B, H), dev)
+    # room for one word per 256-token block of every head: the two-launch form (see include/fastmax_hip.h)
+    wsb, wsp = _ws(max(L.fastmax_hip_normalize_workspace(B, H), 4 * B * H * ((N + 255) // 256)), dev)
     with torch.cuda.device(dev):
         rc = L.fastmax_hip_normalize_cast(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H, N, D,
                                           wsp, wsb.numel(), _stream(dev))

@@ -129,8 +129,9 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
 
 /*      training route: y = (x - mean_D x) / max-norm written in the INPUT dtype (contiguous (B,H,N,D)) -- the reference
  *      keeps 16-bit tensors 16-bit between the prologue and the attention (fastmax_hack.py:38-43) -- plus inv_norm (B,H).
- *      workspace: fastmax_hip_normalize_workspace(B, H).  FASTMAX_E_BAD_SHAPE when D is not a multiple of 16 bytes
- *      of elements (the caller then uses fastmax_hip_normalize).                                                   */
+ *      workspace: fastmax_hip_normalize_workspace(B, H); with 4 B H ceil(N/256) bytes or more the statistics pass writes one
+ *      word per 256-token block and the row pass combines them (two launches instead of four, same values).
+ *      FASTMAX_E_BAD_SHAPE when D is not a multiple of 16 bytes of elements (the caller then uses fastmax_hip_normalize). */
 int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm,
                                int B, int H, int N, int D, void* workspace, size_t workspace_bytes, void* stream);
 /*      backward of the prologue (the reference gets it from autograd over fastmax_hack.py:38-43):

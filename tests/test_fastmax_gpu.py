@@ -719,3 +719,26 @@ def test_backward_reuses_the_forward_prefix_states(shape, dt):
             assert torch.equal(a, b)
         # p = 2 has no carried state: nothing is kept
         assert ops.forward(q, k, v, 2, True, 1.0, 0.0, dt, keep_states=True)[2] is None
+
+
+@pytest.mark.parametrize("shape,dt", [((2, 3, 700, 64), torch.bfloat16), ((1, 2, 256, 32), torch.float32), ((1, 1, 1030, 128), torch.float16)])
+def test_normalize_cast_two_launch_form_matches_the_atomic_form(shape, dt):
+    """fastmax_hip_normalize_cast with room for per-block maxima (two launches) gives the same bits as the zero + atomic-max +
+    finish form it takes with the small workspace"""
+    import ctypes
+    from fastmax_experiments_amd import ops, _lib
+    torch.manual_seed(11)
+    x = (torch.randn(shape, device="cuda") * 3 + 0.5).to(dt)
+    y, inv = ops.normalize_cast(x)
+    L = _lib.lib()
+    B, H, N, D = shape
+    y2 = torch.empty_like(y)
+    inv2 = torch.empty_like(inv)
+    ws = torch.empty(L.fastmax_hip_normalize_workspace(B, H), dtype=torch.uint8, device="cuda")
+    rc = L.fastmax_hip_normalize_cast(x.data_ptr(), ops._strides(x), ops._DT[dt], y2.data_ptr(), inv2.data_ptr(), B, H, N, D,
+                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), ops._stream(x.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(inv, inv2) and torch.equal(y, y2)
+    ref = ops.normalize_stats(x)
+    assert torch.equal(inv, ref)

@@ -191,7 +191,9 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(256), lds, stream, prm);
     const int rec = DP * DP + 2 * DP;
-    hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec, RS ? 1 : 0);
+    // one record per head (two segments) is its own prefix
+    if (prm.nseg > 2)
+        hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec, RS ? 1 : 0);
     return (int)hipGetLastError();
 }
 template <typename TIN, bool NORM>

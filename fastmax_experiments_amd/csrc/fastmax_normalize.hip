@@ -5,8 +5,10 @@
 //     gxc = gy / M;   dL/dM = -sum_{n,d}(gy y) / M;   gxc[n*] += dL/dM y[n*]  (n* = first argmax_n of the row norm);
 //     gx = gxc - mean_D gxc
 // Rows are spread over LPR lanes with 16-byte loads (scalar loads for unaligned views).  The backward is two launches:
-// per-block partials (sum gy.xc, best (norm^2, n)) then the row pass; partials are combined in a fixed order, so the
-// result is bitwise reproducible.
+// the row pass (every row without the dL/dM term + per-block partials sum gy.xc, best (norm^2, n)), then one wave per head
+// that combines the partials in a fixed order (bitwise reproducible) and rewrites the one row that has the extra term.
+#include <stdlib.h>
+
 #include "fastmax_common.h"
 
 namespace fastmax {
@@ -184,6 +186,111 @@ __global__ __launch_bounds__(256) void normalize_bwd_apply_kernel(const void* x,
     }
 }
 
+// ---- backward in one row pass + a one-row fix-up ----------------------------------------------------------------------------
+// Only the row that attains the maximum (n*) sees the dL/dM term, so every row can be written as  gx = inv gy - mean_D(inv gy)
+// in the SAME pass that accumulates the block's  sum gy.xc  and best (||xc||^2, n); a one-workgroup-per-head kernel then
+// combines the partials (fixed order) and rewrites row n* with the full formula.  x and gy are read once instead of twice;
+// same formulas as the reduce + apply pair above (kept for A/B runs); results differ from it by last-bit float32 rounding only
+// (the compiler contracts the two forms differently).
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void normalize_bwd_rows_kernel(const void* x, Strides3 xs, const T* gy, const float* inv_norm, int H, int N,
+                                                                 int D, T* gx, float* part_dot, unsigned long long* part_best, int vec) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+    __shared__ float sdot[4];
+    __shared__ unsigned long long sbest[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid % LPR, rgrp = tid / LPR;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    float dot = 0.f;
+    unsigned long long best = 0ull;
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
+        float v[EPL], gv[EPL];
+        load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += v[e];
+        const float mean = group_sum<LPR>(s) * invD;
+        float nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float c = (sub * EPL + e) < D ? v[e] - mean : 0.f;
+            nn = fmaf(c, c, nn);
+            dot = fmaf(gv[e], c, dot);
+        }
+        nn = group_sum<LPR>(nn);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(nn) << 32) | (unsigned long long)(0xffffffffu - (unsigned)n);
+        best = key > best ? key : best;
+        // the row's gradient without the dL/dM term (exact for every row but n*)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] *= inv;
+        float gs = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gs += gv[e];
+        const float gm = group_sum<LPR>(gs) * invD;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] -= gm;
+        store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) { sdot[wave] = dot; sbest[wave] = best; }
+    __syncthreads();
+    if (tid == 0) {
+        const int idx = bh * gridDim.x + blockIdx.x;
+        part_dot[idx] = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
+        unsigned long long m = sbest[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = sbest[i] > m ? sbest[i] : m;
+        part_best[idx] = m;
+    }
+}
+
+// one wave per head: combine the partials, rewrite row n* with the dL/dM term (the n == nstar branch of the apply kernel)
+template <typename T, int LPR>
+__global__ __launch_bounds__(64) void normalize_bwd_fix_kernel(const void* x, Strides3 xs, const T* gy, const float* inv_norm,
+                                                               const float* part_dot, const unsigned long long* part_best, int nblk, int H,
+                                                               int N, int D, T* gx, int vec) {
+    constexpr int EPL = 16 / sizeof(T);
+    const int tid = threadIdx.x, sub = tid % LPR;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    float S = 0.f;
+    unsigned long long best = 0ull;
+    for (int i = 0; i < nblk; ++i) {                               // fixed order: reproducible
+        S += part_dot[bh * nblk + i];
+        const unsigned long long o = part_best[bh * nblk + i];
+        best = o > best ? o : best;
+    }
+    const int n = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+    const float dLdM = -(S * inv) * inv;
+    if (tid >= LPR || n < 0 || n >= N) return;
+    float gv[EPL], v[EPL];
+    load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) gv[e] *= inv;
+    load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
+    const float mean = group_sum<LPR>(s) * invD;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+        if (sub * EPL + e < D) gv[e] = fmaf(dLdM, (v[e] - mean) * inv, gv[e]);
+    float gs = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) gs += gv[e];
+    const float gm = group_sum<LPR>(gs) * invD;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) gv[e] -= gm;
+    store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+}
+
 static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
     const int epl = (int)(16 / es);
     return (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((xs.sb * es) % 16 == 0) && ((xs.sh * es) % 16 == 0) &&
@@ -235,11 +342,19 @@ static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const flo
     unsigned long long* part_best = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);
     float* part_dot = reinterpret_cast<float*>(part_best + (size_t)B * H * nblk);
     const dim3 grid(nblk, B * H), block(256);
+    static const bool two_pass = getenv("FASTMAX_NORMALIZE_BWD_TWO_PASS") != nullptr;      // the reduce + apply pair, for A/B runs
 #define CALL(L)                                                                                                                   \
-    hipLaunchKernelGGL((normalize_bwd_reduce_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), H, N, D,  \
-                       part_dot, part_best, vec);                                                                                 \
-    hipLaunchKernelGGL((normalize_bwd_apply_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), inv_norm,  \
-                       part_dot, part_best, H, N, D, reinterpret_cast<T*>(gx), vec)
+    if (two_pass) {                                                                                                               \
+        hipLaunchKernelGGL((normalize_bwd_reduce_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), H, N, D, \
+                           part_dot, part_best, vec);                                                                             \
+        hipLaunchKernelGGL((normalize_bwd_apply_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), inv_norm, \
+                           part_dot, part_best, H, N, D, reinterpret_cast<T*>(gx), vec);                                          \
+    } else {                                                                                                                      \
+        hipLaunchKernelGGL((normalize_bwd_rows_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), inv_norm, H, N, \
+                           D, reinterpret_cast<T*>(gx), part_dot, part_best, vec);                                                \
+        hipLaunchKernelGGL((normalize_bwd_fix_kernel<T, L>), dim3(B * H), dim3(64), 0, stream, x, xs, reinterpret_cast<const T*>(gy),   \
+                           inv_norm, part_dot, part_best, nblk, H, N, D, reinterpret_cast<T*>(gx), vec);                          \
+    }
     NRM_LPR_SWITCH(need, CALL)
 #undef CALL
     return (int)hipGetLastError();

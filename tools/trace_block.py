@@ -10,6 +10,9 @@ alg = sys.argv[2] if len(sys.argv) > 2 else "linearmax"
 n_embd, n_head, groups = {"tinyllama": (2048, 32, 4), "llama7b": (4096, 32, 32)}[cfg]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else (8 if cfg == "tinyllama" else 2)
 T = int(sys.argv[4]) if len(sys.argv) > 4 else (2048 if cfg == "tinyllama" else 4096)
+if os.environ.get("FASTMAX_TUNE_GEMMS"):
+    from fastmax_experiments_amd import lora as _lora
+    _lora.enable_gemm_tuning()
 torch.manual_seed(0)
 blk = CausalSelfAttention(n_embd, n_head, n_query_groups=groups, attn_alg=alg).to(torch.bfloat16)
 torch.nn.init.normal_(blk.attn.lora_B, std=0.02)

@@ -25,7 +25,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_linearmax_forward", "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize",
            "fastmax_hip_lora_down", "fastmax_hip_lora_tn_workspace", "fastmax_hip_lora_tn", "fastmax_hip_lora_up",
            "fastmax_hip_forward_state_bytes", "fastmax_hip_backward_with_states",
-           "fastmax_hip_lora_scatter", "fastmax_hip_lora_scatter_backward"]
+           "fastmax_hip_lora_scatter", "fastmax_hip_lora_scatter_backward",
+           "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand"]
 
 
 class Problem(ctypes.Structure):
@@ -107,6 +108,10 @@ def lib():
     L.fastmax_hip_lora_tn.argtypes = [vp, i64, vp, i64, vp, ci, ci, ci, vp, ci, ci, ci, vp]
     L.fastmax_hip_lora_tn.restype = ci
     L.fastmax_hip_lora_up.argtypes = [vp, i64, vp, i64, vp, i64, ci, vp, ci, ci, ci, vp]
+    L.fastmax_hip_normalize_cast_expand.argtypes = [vp, i64p, ci, vp, vp, ci, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_cast_expand.restype = ci
+    L.fastmax_hip_normalize_backward_expand.argtypes = [vp, i64p, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_backward_expand.restype = ci
     L.fastmax_hip_lora_scatter.argtypes = [vp, ci, ci, vp, ci, ctypes.c_float, vp, i64, ci, ci, vp]
     L.fastmax_hip_lora_scatter.restype = ci
     L.fastmax_hip_lora_scatter_backward.argtypes = [vp, ci, i64, vp, vp, ctypes.c_float, vp, ci, ci, ci, vp]

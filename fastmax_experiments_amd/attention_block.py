@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from .attention_mechanisms.fastmax import fastmax
-from .attention_mechanisms.fastmax_hack import fastmax_hack
+from .attention_mechanisms.fastmax_hack import fastmax_hack, fastmax_hack_grouped, grouped_route_supported
 from .lora import LoRALinear, LoRAQKVLinear
 
 
@@ -68,7 +68,18 @@ class CausalSelfAttention(nn.Module):
         total_qkv = q_per_kv + 2
         fused = (self.fused_neighbours and x.device.type == "cuda" and input_pos is None and
                  ops.rope_qkv_supported(qkv.dtype, self.head_size, self.rope_n_elem))
-        if fused:
+        grouped = (fused and self.attn_alg == "linearmax" and q_per_kv > 1 and torch.is_grad_enabled() and
+                   (x.requires_grad or any(p.requires_grad for p in self.attn.parameters())) and
+                   grouped_route_supported(x.device, qkv.dtype, self.head_size, B * self.n_head))
+        if grouped:
+            # training, grouped-query heads: K stays at its n_query_groups heads through RoPE and the linearmax prologue
+            # (statistics and gradient once per key head); the prologue's store writes the per-query-head copies
+            q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
+                                             self.rope_n_elem, 2)
+            y = fastmax_hack_grouped(q, k, v, q_per_kv, p=1)
+            y = y.reshape(B, T, self.head_size * self.n_head)      # model.py:453-455 (no transpose: quirk Q3)
+            return self.proj(y)
+        elif fused:
             # de-interleave + RoPE + GQA expand in one HIP pass, same values as the tensor ops below
             q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
                                              self.rope_n_elem)

@@ -7,6 +7,8 @@ promote low-precision inputs to a float32 result.
 The prologue and the attention both run in libfastmax_hip.so; gradients flow through
 ``_NormalizeQK`` (the reference gets them from plain autograd over its einsum graph).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -19,13 +21,16 @@ class _NormalizeQK(torch.autograd.Function):
     float32 kernel and the tensor-op backward below."""
 
     @staticmethod
-    def forward(ctx, x):
-        r = ops.normalize_cast(x)
+    def forward(ctx, x, rep=1):
+        r = ops.normalize_cast(x, rep)
+        ctx.rep = rep
         if r is not None:
             y, inv = r
             ctx.save_for_backward(x, inv)
             ctx.fused = True
             return y
+        if rep != 1:
+            raise NotImplementedError("grouped normalisation needs a head size that is a whole number of 16-byte pieces")
         y, inv = ops.normalize(x)
         ctx.save_for_backward(y, inv)
         ctx.in_dtype = x.dtype
@@ -36,7 +41,7 @@ class _NormalizeQK(torch.autograd.Function):
     def backward(ctx, gy):
         if ctx.fused:
             x, inv = ctx.saved_tensors
-            return ops.normalize_backward(x, gy, inv)
+            return ops.normalize_backward(x, gy, inv, ctx.rep), None
         y, inv = ctx.saved_tensors                     # y = xc / M, inv = 1 / M
         gy = gy.float()
         gxc = gy * inv[..., None, None]
@@ -46,7 +51,7 @@ class _NormalizeQK(torch.autograd.Function):
         ystar = torch.gather(y, 2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]))
         gxc.scatter_add_(2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]), dLdM[..., None, None] * ystar)
         gx = gxc - gxc.mean(-1, keepdim=True)
-        return gx.to(ctx.in_dtype)
+        return gx.to(ctx.in_dtype), None
 
 
 def fastmax_hack(q, k, v, p=1, mask=True):
@@ -68,7 +73,7 @@ def fastmax_hack(q, k, v, p=1, mask=True):
     # training (or shapes the fused kernel does not cover): prologue and attention as separate autograd nodes,
     # both in libfastmax_hip.so; 16-bit inputs keep their dtype between the two, like the reference
     vd = ops._prep(v.to(kdt), dev)
-    qn, kn = _NormalizeQK.apply(qd), _NormalizeQK.apply(kd)
+    qn, kn = _NormalizeQK.apply(qd, 1), _NormalizeQK.apply(kd, 1)
     if not mask:
         # fastmax_hack.py:6-33: first order whatever p is; constant term N_k; result float32 for
         # low-precision inputs (float32 ones at line 21), float64 stays float64
@@ -78,6 +83,24 @@ def fastmax_hack(q, k, v, p=1, mask=True):
         o = fastattention_einops.apply(qn, kn, vd, True, 1, True, p, 0.0, False)
         out_dt = in_dtype
     return o.to(device=home, dtype=out_dt)
+
+
+def fastmax_hack_grouped(q, k_groups, v, rep, p=1):
+    """Masked linearmax for grouped-query attention on the training route: q (B,H,N,D), v (B,H,N,D) already repeated,
+    k_groups (B,G,N,D) with H = G * rep.  Same values as fastmax_hack(q, expand(k_groups), v, p, mask=True): the max-norm
+    statistics of identical head copies are identical, so the prologue runs once per key head and writes the H copies the
+    attention reads (the reference expands first, model.py:404-411, and normalises every copy, fastmax_hack.py:38-43)."""
+    qn = _NormalizeQK.apply(q, 1)
+    kn = _NormalizeQK.apply(k_groups, rep)
+    o = fastattention_einops.apply(qn, kn, v, True, 1, True, p, 0.0, False)
+    return o.to(q.dtype)
+
+
+def grouped_route_supported(device, dtype, head_size, heads) -> bool:
+    """can fastmax_hack_grouped serve (B * H = heads) heads of this dtype / head size?  (FASTMAX_GROUPED_K=0 turns it off)"""
+    return (os.environ.get("FASTMAX_GROUPED_K", "1") != "0" and device.type == "cuda" and
+            dtype in (torch.bfloat16, torch.float16, torch.float32) and
+            (head_size * torch.empty((), dtype=dtype).element_size()) % 16 == 0 and heads <= MAX_HEADS_PER_LAUNCH)
 
 
 class _UnmaskedNk(torch.autograd.Function):

@@ -214,6 +214,35 @@ int fastmax_hip_normalize_backward(const void* x, const int64_t* x_strides, int 
                                      reinterpret_cast<hipStream_t>(stream));
 }
 
+// grouped-query form of the two entry points above: x holds the G key heads, y / grad_y the G * rep query-head copies
+// (head g * rep + j) that the attention reads -- the GQA expand of lit_gpt/model.py:404-411 fused into the prologue's store,
+// and the sum over a group's heads fused into its backward
+int fastmax_hip_normalize_cast_expand(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm, int B, int G,
+                                      int rep, int N, int D, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !x_strides || !y || !inv_norm) return FASTMAX_E_NULL;
+    if (B <= 0 || G <= 0 || rep <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
+    const int es = dtype == FASTMAX_F32 ? 4 : 2;
+    if (D * es > 512) return FASTMAX_E_BAD_SHAPE;
+    const int npart = (N + 255) / 256;
+    if (!workspace || workspace_bytes < sizeof(unsigned int) * (size_t)B * G * npart) return FASTMAX_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned int* partials = reinterpret_cast<unsigned int*>(workspace);
+    const int rc = launch_normalize_partial_max(x, st(x_strides), dtype, partials, B, G, N, D, s);
+    if (rc) return rc;
+    return launch_normalize_cast(x, st(x_strides), dtype, y, nullptr, B, G, N, D, s, partials, npart, inv_norm, rep);
+}
+
+int fastmax_hip_normalize_backward_expand(const void* x, const int64_t* x_strides, int dtype, const void* grad_y,
+                                          const float* inv_norm, void* grad_x, int B, int G, int rep, int N, int D, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    if (!x || !x_strides || !grad_y || !inv_norm || !grad_x) return FASTMAX_E_NULL;
+    if (B <= 0 || G <= 0 || rep <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < normalize_backward_workspace(B, G * rep, N)) return FASTMAX_E_WORKSPACE;
+    return launch_normalize_backward(x, st(x_strides), dtype, grad_y, inv_norm, grad_x, B, G, N, D, workspace,
+                                     reinterpret_cast<hipStream_t>(stream), rep);
+}
+
 int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                   const int64_t* k_strides, const void* v, const int64_t* v_strides,
                                   const float* q_inv_norm, const float* k_inv_norm, void* o, float* g, void* workspace,

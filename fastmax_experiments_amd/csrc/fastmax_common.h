@@ -107,12 +107,12 @@ int launch_fwd_mfma_bf16(const FwdArgs& a, const float* qscale, const float* ksc
 bool mfma_bf16_supported(const fastmax_problem& p);
 bool mfma_gen_supported(const fastmax_problem& p, bool norm);
 int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const float* inv_norm, int B, int H, int N, int D,
-                          hipStream_t stream, const unsigned int* partials = nullptr, int npart = 0, float* inv_out = nullptr);
+                          hipStream_t stream, const unsigned int* partials = nullptr, int npart = 0, float* inv_out = nullptr, int rep = 1);
 int launch_normalize_partial_max(const void* x, Strides3 xs, int dtype, unsigned int* partials, int B, int H, int N, int D,
                                  hipStream_t stream);
 size_t normalize_backward_workspace(int B, int H, int N);
 int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void* gy, const float* inv_norm, void* gx, int B, int H,
-                              int N, int D, void* ws, hipStream_t stream);
+                              int N, int D, void* ws, hipStream_t stream, int rep = 1);
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
                            void* workspace, hipStream_t stream);
 // sequence split of the linear-time kernels when B*H alone cannot fill the chip

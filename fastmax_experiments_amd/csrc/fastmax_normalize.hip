@@ -61,8 +61,8 @@ template <int LPR> __device__ __forceinline__ float group_sum(float s) {
 // ---- forward: y (dtype T, contiguous) = (x - mean) * inv[bh];  grid = (ceil(N / (256/LPR) / RPT), B*H) -----------------
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_cast_kernel(const void* x, Strides3 xs, int H, int N, int D, const float* inv_norm,
-                                                             T* y, int vec, const unsigned int* partials, int npart, float* inv_out) {
-    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+                                                             T* y, int vec, const unsigned int* partials, int npart, float* inv_out, int rep, int tok) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR;
     const int tid = threadIdx.x, sub = tid % LPR, rgrp = tid / LPR;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     float inv;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const void* x, Stri
         inv = inv_norm[bh];
     }
     const float invD = 1.0f / (float)D;
-    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    const int n_begin = blockIdx.x * tok, n_end = min(N, n_begin + tok);
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         float v[EPL];
         load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(const void* x, Stri
         const float mean = group_sum<LPR>(s) * invD;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mean) * inv;
-        store_row_piece<T>(y + ((int64_t)bh * N + n) * D, sub, D, vec, v);
+        // rep > 1: the row is written for the rep query heads that share this key head (GQA expand fused into the store)
+        for (int j = 0; j < rep; ++j) store_row_piece<T>(y + (((int64_t)bh * rep + j) * N + n) * D, sub, D, vec, v);
     }
 }
 
@@ -194,20 +195,26 @@ __global__ __launch_bounds__(256) void normalize_bwd_apply_kernel(const void* x,
 // (the compiler contracts the two forms differently).
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_bwd_rows_kernel(const void* x, Strides3 xs, const T* gy, const float* inv_norm, int H, int N,
-                                                                 int D, T* gx, float* part_dot, unsigned long long* part_best, int vec) {
-    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR, TOK = 256;
+                                                                 int D, T* gx, float* part_dot, unsigned long long* part_best, int vec, int rep, int tok) {
+    constexpr int EPL = 16 / sizeof(T), RPB = 256 / LPR;
     __shared__ float sdot[4];
     __shared__ unsigned long long sbest[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid % LPR, rgrp = tid / LPR;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const float inv = inv_norm[bh], invD = 1.0f / (float)D;
-    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    const int n_begin = blockIdx.x * tok, n_end = min(N, n_begin + tok);
     float dot = 0.f;
     unsigned long long best = 0ull;
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         float v[EPL], gv[EPL];
         load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
-        load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+        load_row_piece<T>(gy + (((int64_t)bh * rep) * N + n) * D, sub, D, vec, gv);
+        for (int j = 1; j < rep; ++j) {                            // y was written for rep heads: their gradients add up
+            float gj[EPL];
+            load_row_piece<T>(gy + (((int64_t)bh * rep + j) * N + n) * D, sub, D, vec, gj);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) gv[e] += gj[e];
+        }
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) s += v[e];
@@ -255,23 +262,36 @@ __global__ __launch_bounds__(256) void normalize_bwd_rows_kernel(const void* x, 
 template <typename T, int LPR>
 __global__ __launch_bounds__(64) void normalize_bwd_fix_kernel(const void* x, Strides3 xs, const T* gy, const float* inv_norm,
                                                                const float* part_dot, const unsigned long long* part_best, int nblk, int H,
-                                                               int N, int D, T* gx, int vec) {
+                                                               int N, int D, T* gx, int vec, int rep) {
     constexpr int EPL = 16 / sizeof(T);
     const int tid = threadIdx.x, sub = tid % LPR;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    // lane l takes partials l, l + 64, ...; the lanes are combined by a fixed butterfly: the same order every run
     float S = 0.f;
     unsigned long long best = 0ull;
-    for (int i = 0; i < nblk; ++i) {                               // fixed order: reproducible
-        S += part_dot[bh * nblk + i];
-        const unsigned long long o = part_best[bh * nblk + i];
+    for (int i = tid; i < nblk; i += 64) {
+        S += part_dot[(int64_t)bh * nblk + i];
+        const unsigned long long o = part_best[(int64_t)bh * nblk + i];
+        best = o > best ? o : best;
+    }
+    S = wave_sum(S);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
         best = o > best ? o : best;
     }
     const int n = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
     const float dLdM = -(S * inv) * inv;
     if (tid >= LPR || n < 0 || n >= N) return;
     float gv[EPL], v[EPL];
-    load_row_piece<T>(gy + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+    load_row_piece<T>(gy + (((int64_t)bh * rep) * N + n) * D, sub, D, vec, gv);
+    for (int j = 1; j < rep; ++j) {
+        float gj[EPL];
+        load_row_piece<T>(gy + (((int64_t)bh * rep + j) * N + n) * D, sub, D, vec, gj);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] += gj[e];
+    }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) gv[e] *= inv;
     load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
@@ -304,13 +324,15 @@ static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
 
 template <typename T>
 static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream,
-                            const unsigned int* partials, int npart, float* inv_out) {
+                            const unsigned int* partials, int npart, float* inv_out, int rep) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
     if (need > 32) return FASTMAX_E_BAD_SHAPE;
     // 16-byte accesses need whole pieces per row and aligned rows on both sides; otherwise element-wise loads / stores
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(y) & 15);
-    const dim3 grid((N + 255) / 256, B * H), block(256);
-#define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec, partials, npart, inv_out)
+    // rep > 1: each row is stored rep times, so blocks take 256 / rep tokens (at least 32) to keep the grid as large
+    const int tok = rep > 1 ? (256 / rep < 32 ? 32 : 256 / rep) : 256;
+    const dim3 grid((N + tok - 1) / tok, B * H), block(256);
+#define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec, partials, npart, inv_out, rep, tok)
     NRM_LPR_SWITCH(need, CALL)
 #undef CALL
     return (int)hipGetLastError();
@@ -318,11 +340,12 @@ static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* in
 // partials == nullptr: inv_norm is an input.  Else inv_norm is computed from the npart per-block maxima of each head
 // (launch_normalize_partial_max) and written to inv_out
 int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const float* inv_norm, int B, int H, int N, int D,
-                          hipStream_t stream, const unsigned int* partials, int npart, float* inv_out) {
+                          hipStream_t stream, const unsigned int* partials, int npart, float* inv_out, int rep) {
+    if (rep < 1) return FASTMAX_E_BAD_SHAPE;
     switch (dtype) {
-        case FASTMAX_F32: return normalize_cast_t<float>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
-        case FASTMAX_BF16: return normalize_cast_t<bf16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
-        case FASTMAX_F16: return normalize_cast_t<f16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out);
+        case FASTMAX_F32: return normalize_cast_t<float>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out, rep);
+        case FASTMAX_BF16: return normalize_cast_t<bf16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out, rep);
+        case FASTMAX_F16: return normalize_cast_t<f16_t>(x, xs, y, inv_norm, B, H, N, D, stream, partials, npart, inv_out, rep);
     }
     return FASTMAX_E_BAD_DTYPE;
 }
@@ -333,16 +356,20 @@ size_t normalize_backward_workspace(int B, int H, int N) {
 
 template <typename T>
 static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const float* inv_norm, void* gx, int B, int H, int N, int D,
-                           void* ws, hipStream_t stream) {
+                           void* ws, hipStream_t stream, int rep) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
     if (need > 32) return FASTMAX_E_BAD_SHAPE;
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15);
-    const int nblk = (N + 255) / 256;
+    // rep > 1 (grouped-query form): every row reads rep gradient rows, so blocks take 256 / rep tokens (at least 32); the
+    // partial records then number what the expanded tensor would need (the caller sizes the workspace for B, H rep, N)
+    const int tok = rep > 1 ? (256 / rep < 32 ? 32 : 256 / rep) : 256;
+    const int nblk = (N + tok - 1) / tok;
     // 8-byte records first (alignment), then the floats
     unsigned long long* part_best = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);
     float* part_dot = reinterpret_cast<float*>(part_best + (size_t)B * H * nblk);
     const dim3 grid(nblk, B * H), block(256);
-    static const bool two_pass = getenv("FASTMAX_NORMALIZE_BWD_TWO_PASS") != nullptr;      // the reduce + apply pair, for A/B runs
+    static const bool two_pass_env = getenv("FASTMAX_NORMALIZE_BWD_TWO_PASS") != nullptr;  // the reduce + apply pair, for A/B runs
+    const bool two_pass = two_pass_env && rep == 1;
 #define CALL(L)                                                                                                                   \
     if (two_pass) {                                                                                                               \
         hipLaunchKernelGGL((normalize_bwd_reduce_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), H, N, D, \
@@ -351,20 +378,21 @@ static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const flo
                            part_dot, part_best, H, N, D, reinterpret_cast<T*>(gx), vec);                                          \
     } else {                                                                                                                      \
         hipLaunchKernelGGL((normalize_bwd_rows_kernel<T, L>), grid, block, 0, stream, x, xs, reinterpret_cast<const T*>(gy), inv_norm, H, N, \
-                           D, reinterpret_cast<T*>(gx), part_dot, part_best, vec);                                                \
+                           D, reinterpret_cast<T*>(gx), part_dot, part_best, vec, rep, tok);                                      \
         hipLaunchKernelGGL((normalize_bwd_fix_kernel<T, L>), dim3(B * H), dim3(64), 0, stream, x, xs, reinterpret_cast<const T*>(gy),   \
-                           inv_norm, part_dot, part_best, nblk, H, N, D, reinterpret_cast<T*>(gx), vec);                          \
+                           inv_norm, part_dot, part_best, nblk, H, N, D, reinterpret_cast<T*>(gx), vec, rep);                     \
     }
     NRM_LPR_SWITCH(need, CALL)
 #undef CALL
     return (int)hipGetLastError();
 }
 int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void* gy, const float* inv_norm, void* gx, int B, int H,
-                              int N, int D, void* ws, hipStream_t stream) {
+                              int N, int D, void* ws, hipStream_t stream, int rep) {
+    if (rep < 1) return FASTMAX_E_BAD_SHAPE;
     switch (dtype) {
-        case FASTMAX_F32: return normalize_bwd_t<float>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
-        case FASTMAX_BF16: return normalize_bwd_t<bf16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
-        case FASTMAX_F16: return normalize_bwd_t<f16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream);
+        case FASTMAX_F32: return normalize_bwd_t<float>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream, rep);
+        case FASTMAX_BF16: return normalize_bwd_t<bf16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream, rep);
+        case FASTMAX_F16: return normalize_bwd_t<f16_t>(x, xs, gy, inv_norm, gx, B, H, N, D, ws, stream, rep);
     }
     return FASTMAX_E_BAD_DTYPE;
 }

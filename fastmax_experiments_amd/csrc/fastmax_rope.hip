@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(RopeParams prm) {
     const bool is_q = slot < prm.qpk, is_k = slot == prm.qpk;
     // destination(s) (forward) / source(s) (backward) in the (B, heads, T, hs) tensors
     T* base = reinterpret_cast<T*>(is_q ? prm.q : (is_k ? prm.k : prm.v));
-    const int heads = (is_q || prm.expand_kv) ? H : prm.G;
-    const int h0 = is_q ? g * prm.qpk + slot : (prm.expand_kv ? g * prm.qpk : g);
-    const int ncopy = (!is_q && prm.expand_kv) ? prm.qpk : 1;
+    // expand_kv: 0 = k, v stay at their G heads, 1 = both repeated for the q_per_kv query heads of their group, 2 = only v
+    const bool expand = !is_q && (prm.expand_kv == 1 || (prm.expand_kv == 2 && !is_k));
+    const int heads = (is_q || expand) ? H : prm.G;
+    const int h0 = is_q ? g * prm.qpk + slot : (expand ? g * prm.qpk : g);
+    const int ncopy = expand ? prm.qpk : 1;
     const int64_t hstride = (int64_t)prm.T * hs;
     T* hrow = base + (((int64_t)b * heads + h0) * prm.T + t) * hs;
     const bool rotate = !(!is_q && !is_k) && unit < pair_units;      // v is never rotated

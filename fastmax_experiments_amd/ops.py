@@ -132,36 +132,45 @@ def normalize(x):
     return y, inv
 
 
-def normalize_cast(x):
+def normalize_cast(x, rep=1):
     """linearmax prologue written in x's own dtype (training route): -> (y like x, contiguous; inv_norm (B,H) float32),
-    or None when the head size is not a whole number of 16-byte pieces (caller falls back to normalize())."""
+    or None when the head size is not a whole number of 16-byte pieces (caller falls back to normalize()).
+    rep > 1 (grouped-query attention): x holds the G key heads, y the G * rep query-head copies (B, G * rep, N, D)."""
     L = _lib.lib()
     dev = x.device
     B, H, N, D = x.shape
-    y = torch.empty((B, H, N, D), dtype=x.dtype, device=dev)
+    y = torch.empty((B, H * rep, N, D), dtype=x.dtype, device=dev)
     inv = torch.empty((B, H), dtype=torch.float32, device=dev)
     # room for one word per 256-token block of every head: the two-launch form (see include/fastmax_hip.h)
     wsb, wsp = _ws(max(L.fastmax_hip_normalize_workspace(B, H), 4 * B * H * ((N + 255) // 256)), dev)
     with torch.cuda.device(dev):
-        rc = L.fastmax_hip_normalize_cast(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H, N, D,
-                                          wsp, wsb.numel(), _stream(dev))
+        if rep == 1:
+            rc = L.fastmax_hip_normalize_cast(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H, N, D,
+                                              wsp, wsb.numel(), _stream(dev))
+        else:
+            rc = L.fastmax_hip_normalize_cast_expand(x.data_ptr(), _strides(x), _DT[x.dtype], y.data_ptr(), inv.data_ptr(), B, H,
+                                                     rep, N, D, wsp, wsb.numel(), _stream(dev))
     if rc == _lib.E_BAD_SHAPE:
         return None
     _lib.check(rc, "fastmax_hip_normalize_cast")
     return y, inv
 
 
-def normalize_backward(x, gy, inv):
-    """gradient of normalize_cast wrt x; gy like x (made contiguous), inv from the forward."""
+def normalize_backward(x, gy, inv, rep=1):
+    """gradient of normalize_cast wrt x; gy like y (made contiguous), inv from the forward."""
     L = _lib.lib()
     dev = x.device
     B, H, N, D = x.shape
     gy = gy.to(x.dtype).contiguous()
     gx = torch.empty((B, H, N, D), dtype=x.dtype, device=dev)
-    wsb, wsp = _ws(L.fastmax_hip_normalize_backward_workspace(B, H, N), dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_backward_workspace(B, H * rep, N), dev)
     with torch.cuda.device(dev):
-        rc = L.fastmax_hip_normalize_backward(x.data_ptr(), _strides(x), _DT[x.dtype], gy.data_ptr(), inv.data_ptr(),
-                                              gx.data_ptr(), B, H, N, D, wsp, wsb.numel(), _stream(dev))
+        if rep == 1:
+            rc = L.fastmax_hip_normalize_backward(x.data_ptr(), _strides(x), _DT[x.dtype], gy.data_ptr(), inv.data_ptr(),
+                                                  gx.data_ptr(), B, H, N, D, wsp, wsb.numel(), _stream(dev))
+        else:
+            rc = L.fastmax_hip_normalize_backward_expand(x.data_ptr(), _strides(x), _DT[x.dtype], gy.data_ptr(), inv.data_ptr(),
+                                                         gx.data_ptr(), B, H, rep, N, D, wsp, wsb.numel(), _stream(dev))
     _lib.check(rc, "fastmax_hip_normalize_backward")
     return gx
 
@@ -217,32 +226,37 @@ class RopeQKVSplit(torch.autograd.Function):
     (fastmax_rope.hip; lit_gpt/model.py:397-425), and the mirror pass for the gradient."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, rope_n_elem):
+    def forward(ctx, qkv, cos, sin, rope_n_elem, expand=1):
+        """expand: 1 = k and v repeated for the query heads of their group (B,H,T,hs); 2 = only v, k stays (B,G,T,hs);
+        0 = neither"""
         L = _lib.lib()
         B, T, G, total, hs = qkv.shape
         qpk = total - 2
         qkv = qkv.contiguous()
         cos = cos[:T, :rope_n_elem].float().contiguous()
         sin = sin[:T, :rope_n_elem].float().contiguous()
-        q, k, v = (torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device) for _ in range(3))
+        q = torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device)
+        k = torch.empty((B, G * qpk if expand == 1 else G, T, hs), dtype=qkv.dtype, device=qkv.device)
+        v = torch.empty((B, G * qpk if expand in (1, 2) else G, T, hs), dtype=qkv.dtype, device=qkv.device)
         with torch.cuda.device(qkv.device):
             rc = L.fastmax_hip_rope_qkv_split(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
-                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, 1, _DT[qkv.dtype], _stream(qkv.device))
+                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, int(expand), _DT[qkv.dtype],
+                                              _stream(qkv.device))
         _lib.check(rc, "fastmax_hip_rope_qkv_split")
         ctx.save_for_backward(cos, sin)
-        ctx.dims = (B, T, G, qpk, hs, rope_n_elem)
+        ctx.dims = (B, T, G, qpk, hs, rope_n_elem, int(expand))
         return q, k, v
 
     @staticmethod
     def backward(ctx, gq, gk, gv):
         L = _lib.lib()
         cos, sin = ctx.saved_tensors
-        B, T, G, qpk, hs, rope_n_elem = ctx.dims
+        B, T, G, qpk, hs, rope_n_elem, expand = ctx.dims
         gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
         gqkv = torch.empty((B, T, G, qpk + 2, hs), dtype=gq.dtype, device=gq.device)
         with torch.cuda.device(gq.device):
             rc = L.fastmax_hip_rope_qkv_split_backward(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                       gqkv.data_ptr(), B, T, G, qpk, hs, rope_n_elem, 1, _DT[gq.dtype],
+                                                       gqkv.data_ptr(), B, T, G, qpk, hs, rope_n_elem, expand, _DT[gq.dtype],
                                                        _stream(gq.device))
         _lib.check(rc, "fastmax_hip_rope_qkv_split_backward")
-        return gqkv, None, None, None
+        return gqkv, None, None, None, None

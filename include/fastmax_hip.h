@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -141,6 +141,17 @@ size_t fastmax_hip_normalize_backward_workspace(int B, int H, int N);
 int fastmax_hip_normalize_backward(const void* x, const int64_t* x_strides, int dtype, const void* grad_y,
                                    const float* inv_norm, void* grad_x, int B, int H, int N, int D,
                                    void* workspace, size_t workspace_bytes, void* stream);
+/*      grouped-query form (GQA, lit_gpt/model.py:404-411): x holds the G key heads; y / grad_y hold the G * rep query-head
+ *      copies (head g * rep + j) the attention reads.  The expand is fused into the forward's store, the sum over a group's
+ *      heads into the backward; statistics and gradient are computed once per key head.  workspace: at least
+ *      4 B G ceil(N/256) bytes (forward) / fastmax_hip_normalize_backward_workspace(B, G rep, N) (backward).                 */
+int fastmax_hip_normalize_cast_expand(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm,
+                                      int B, int G, int rep, int N, int D, void* workspace, size_t workspace_bytes,
+                                      void* stream);
+int fastmax_hip_normalize_backward_expand(const void* x, const int64_t* x_strides, int dtype, const void* grad_y,
+                                          const float* inv_norm, void* grad_x, int B, int G, int rep, int N, int D,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* ---- fused linearmax forward: fastmax_hack.py:36-60 (masked branch) in one pass over Q, K, V --
  *      the mean-centre / max-norm prologue is applied to the Q and K rows as they are staged, with the

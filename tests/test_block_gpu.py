@@ -167,3 +167,67 @@ def test_block_with_and_without_fused_neighbours():
         grads.append(xx.grad.float().cpu().numpy())
     assert rel_err(outs[0], outs[1]) < 5e-3
     assert rel_err(grads[0], grads[1]) < 1e-2
+
+
+def test_grouped_query_prologue_matches_expand_then_normalise():
+    """fastmax_hack_grouped (K normalised once per key head, the prologue's store writes the per-query-head copies, its backward
+    sums a group's gradients) == fastmax_hack on the expanded K, forward and all three gradients; and RopeQKVSplit with
+    expand=2 leaves K at its groups with the same values"""
+    from fastmax_experiments_amd import ops
+    from fastmax_experiments_amd.attention_mechanisms.fastmax_hack import fastmax_hack, fastmax_hack_grouped
+    torch.manual_seed(21)
+    B, G, rep, T, hs = 2, 2, 4, 600, 64
+    q0 = torch.randn(B, G * rep, T, hs, device="cuda", dtype=torch.bfloat16)
+    kg0 = torch.randn(B, G, T, hs, device="cuda", dtype=torch.bfloat16)
+    v0 = torch.randn(B, G * rep, T, hs, device="cuda", dtype=torch.bfloat16)
+    go = torch.randn(B, G * rep, T, hs, device="cuda", dtype=torch.bfloat16)
+    res = []
+    for grouped in (True, False):
+        q, kg, v = (t.clone().requires_grad_(True) for t in (q0, kg0, v0))
+        if grouped:
+            o = fastmax_hack_grouped(q, kg, v, rep, p=1)
+        else:
+            k = kg[:, :, None].expand(B, G, rep, T, hs).reshape(B, G * rep, T, hs)
+            o = fastmax_hack(q, k, v, p=1, mask=True)
+        o.backward(go)
+        res.append((o.detach(), q.grad, kg.grad, v.grad))
+    for a, b in zip(*res):
+        assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= 2e-2 * float(b.float().abs().max())
+    # the values the attention sees are the same bits: normalised copies
+    y1, _ = ops.normalize_cast(kg0, rep)
+    y2, _ = ops.normalize_cast(kg0[:, :, None].expand(B, G, rep, T, hs).reshape(B, G * rep, T, hs).contiguous())
+    assert torch.equal(y1, y2)
+    # rope split with K left at its groups
+    qkv = torch.randn(B, T, G, rep + 2, hs, device="cuda", dtype=torch.bfloat16)
+    from fastmax_experiments_amd.attention_block import build_rope_cache
+    cos, sin = build_rope_cache(T, hs, device="cuda")
+    qa, ka, va = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 1)
+    qb, kb, vb = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 2)
+    assert kb.shape == (B, G, T, hs) and torch.equal(qa, qb) and torch.equal(va, vb)
+    assert torch.equal(ka.view(B, G, rep, T, hs)[:, :, 0], kb) and torch.equal(ka.view(B, G, rep, T, hs)[:, :, rep - 1], kb)
+
+
+def test_block_grouped_route_matches_the_expanded_route(monkeypatch):
+    """CausalSelfAttention (linearmax, grouped-query heads, training): the route that keeps K at its groups through the prologue
+    against the same block with that route disabled -- output and gradients"""
+    import fastmax_experiments_amd.attention_block as ab
+    torch.manual_seed(22)
+    blk = ab.CausalSelfAttention(256, 8, n_query_groups=2, attn_alg="linearmax").to(torch.bfloat16)
+    torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
+    blk.quantize_base().cuda()
+    T = 700
+    cos, sin = ab.build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    x0 = torch.randn(2, T, 256, device="cuda", dtype=torch.bfloat16)
+    gy = torch.randn(2, T, 256, device="cuda", dtype=torch.bfloat16)
+    res = []
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setattr(ab, "grouped_route_supported", lambda *a: False)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x, cos, sin)
+        y.backward(gy)
+        res.append((y.detach(), x.grad, blk.attn.lora_A.grad.clone(), blk.attn.lora_B.grad.clone()))
+        for p in blk.parameters():
+            p.grad = None
+    for a, b in zip(*res):
+        assert float((a.float() - b.float()).abs().max()) <= 3e-2 * float(b.float().abs().max())

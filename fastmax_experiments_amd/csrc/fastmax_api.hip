@@ -238,7 +238,7 @@ int fastmax_hip_normalize_backward_expand(const void* x, const int64_t* x_stride
                                           size_t workspace_bytes, void* stream) {
     if (!x || !x_strides || !grad_y || !inv_norm || !grad_x) return FASTMAX_E_NULL;
     if (B <= 0 || G <= 0 || rep <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
-    if (!workspace || workspace_bytes < normalize_backward_workspace(B, G * rep, N)) return FASTMAX_E_WORKSPACE;
+    if (!workspace || workspace_bytes < normalize_backward_workspace_grouped(B, G, rep, N)) return FASTMAX_E_WORKSPACE;
     return launch_normalize_backward(x, st(x_strides), dtype, grad_y, inv_norm, grad_x, B, G, N, D, workspace,
                                      reinterpret_cast<hipStream_t>(stream), rep);
 }

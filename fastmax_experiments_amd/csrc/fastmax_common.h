@@ -111,6 +111,8 @@ int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const 
 int launch_normalize_partial_max(const void* x, Strides3 xs, int dtype, unsigned int* partials, int B, int H, int N, int D,
                                  hipStream_t stream);
 size_t normalize_backward_workspace(int B, int H, int N);
+size_t normalize_backward_workspace_grouped(int B, int G, int rep, int N);
+int normalize_block_tokens(int rep);
 int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void* gy, const float* inv_norm, void* gx, int B, int H,
                               int N, int D, void* ws, hipStream_t stream, int rep = 1);
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,

@@ -329,8 +329,8 @@ static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* in
     if (need > 32) return FASTMAX_E_BAD_SHAPE;
     // 16-byte accesses need whole pieces per row and aligned rows on both sides; otherwise element-wise loads / stores
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(y) & 15);
-    // rep > 1: each row is stored rep times, so blocks take 256 / rep tokens (at least 32) to keep the grid as large
-    const int tok = rep > 1 ? (256 / rep < 32 ? 32 : 256 / rep) : 256;
+    // rep > 1: each row is stored rep times, so blocks take ~256 / rep tokens (at least 32) to keep the grid as large
+    const int tok = normalize_block_tokens(rep);
     const dim3 grid((N + tok - 1) / tok, B * H), block(256);
 #define CALL(L) hipLaunchKernelGGL((normalize_cast_kernel<T, L>), grid, block, 0, stream, x, xs, H, N, D, inv_norm, reinterpret_cast<T*>(y), vec, partials, npart, inv_out, rep, tok)
     NRM_LPR_SWITCH(need, CALL)
@@ -350,8 +350,22 @@ int launch_normalize_cast(const void* x, Strides3 xs, int dtype, void* y, const 
     return FASTMAX_E_BAD_DTYPE;
 }
 
-size_t normalize_backward_workspace(int B, int H, int N) {
-    return (size_t)B * H * ((N + 255) / 256) * (sizeof(float) + sizeof(unsigned long long)) + 16;
+// Tokens per workgroup of the prologue's row passes.  rep > 1 (grouped-query form) shortens the block because every row is
+// stored / read rep times.  ceil(256 / rep), not floor: ceil(N / tok) <= rep * ceil(N / 256) then holds for every rep, so the
+// per-block records of the backward always fit a workspace sized for the expanded (B, G * rep, N) tensor.
+int normalize_block_tokens(int rep) {
+    if (rep <= 1) return 256;
+    const int t = (256 + rep - 1) / rep;
+    return t < 32 ? 32 : t;
+}
+static size_t normalize_backward_records(int B, int H, int nblk) {
+    return (size_t)B * H * nblk * (sizeof(float) + sizeof(unsigned long long)) + 16;
+}
+size_t normalize_backward_workspace(int B, int H, int N) { return normalize_backward_records(B, H, (N + 255) / 256); }
+// exact requirement of the grouped-query form (x has G heads, the gradient G * rep): one record per launched block
+size_t normalize_backward_workspace_grouped(int B, int G, int rep, int N) {
+    const int tok = normalize_block_tokens(rep);
+    return normalize_backward_records(B, G, (N + tok - 1) / tok);
 }
 
 template <typename T>
@@ -362,7 +376,7 @@ static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const flo
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15);
     // rep > 1 (grouped-query form): every row reads rep gradient rows, so blocks take 256 / rep tokens (at least 32); the
     // partial records then number what the expanded tensor would need (the caller sizes the workspace for B, H rep, N)
-    const int tok = rep > 1 ? (256 / rep < 32 ? 32 : 256 / rep) : 256;
+    const int tok = normalize_block_tokens(rep);
     const int nblk = (N + tok - 1) / tok;
     // 8-byte records first (alignment), then the floats
     unsigned long long* part_best = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);

@@ -501,53 +501,50 @@ class LoRAQKVLinear(LoRALinear):
         super(LoRALinear, self).__init__(r=r, lora_alpha=lora_alpha, lora_dropout=lora_dropout)
         self.linear = torch.nn.Linear(in_features, out_features, **kwargs)
         self.n_head, self.n_query_groups = n_head, n_query_groups
-        if isinstance(enable_lora, bool):
-            enable_lora = [enable_lora] * 3
-        assert len(enable_lora) == 3
-        self.enable_lora = enable_lora
-        if r > 0 and any(enable_lora):
-            self.lora_A = nn.Parameter(torch.zeros((r * sum(enable_lora), in_features)))
-            enable_q, enable_k, enable_v = enable_lora
-            self.kv_embd_size = self.linear.in_features // (n_head // n_query_groups)
-            qkv_shapes = (self.linear.in_features * enable_q, self.kv_embd_size * enable_k, self.kv_embd_size * enable_v)
-            self.qkv_shapes = [s for s in qkv_shapes if s]
+        self.enable_lora = list(enable_lora) if not isinstance(enable_lora, bool) else [enable_lora] * 3
+        if len(self.enable_lora) != 3:
+            raise ValueError("enable_lora is one flag, or one flag each for q, k and v")
+        if r > 0 and any(self.enable_lora):
+            # The fused projection's columns come in n_query_groups runs of (q_per_kv query heads, one key head, one value
+            # head), head_size columns each (lit_gpt/model.py:397-403).  slot[c] = position of column c's head in its run.
+            q_per_kv = n_head // n_query_groups
+            head_size = out_features // (n_query_groups * (q_per_kv + 2))
+            slot = (torch.arange(out_features) // head_size) % (q_per_kv + 2)
+            owner = torch.where(slot < q_per_kv, 0, slot - q_per_kv + 1)          # 0 = q, 1 = k, 2 = v for every column
+            cols = [torch.nonzero(owner == part).flatten() for part in range(3) if self.enable_lora[part]]
+            # names the reference's consumers read (lora.py:240-278): rows of lora_B per enabled part, and their columns
+            self.kv_embd_size = n_query_groups * head_size
+            self.qkv_shapes = [int(c.numel()) for c in cols]
+            self.lora_ind = torch.cat(cols).tolist()
+            self.lora_A = nn.Parameter(torch.zeros((r * len(cols), in_features)))
             self.lora_B = nn.Parameter(torch.zeros(sum(self.qkv_shapes), r))
             self.scaling = self.lora_alpha / self.r
-            # which output columns each enabled part owns in the interleaved [Q..Q K V | Q..Q K V | ...] layout
-            q_per_kv = self.n_head // self.n_query_groups
-            total_qkv = q_per_kv + 2
-            head_size = out_features // (self.n_query_groups * total_qkv)
-            ind = range(out_features)
-            self.lora_ind = []
-            if enable_q:
-                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv < total_qkv - 2)
-            if enable_k:
-                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv == total_qkv - 2)
-            if enable_v:
-                self.lora_ind.extend(x for x in ind if (x // head_size) % total_qkv == total_qkv - 1)
-            # column block (0..n_enabled-1) of every lora_B row: rows are ordered part by part
-            part = torch.repeat_interleave(torch.arange(len(self.qkv_shapes)), torch.tensor(self.qkv_shapes))
-            self.register_buffer("_ind", torch.tensor(self.lora_ind, dtype=torch.long), persistent=False)
-            self.register_buffer("_cols", part[:, None] * r + torch.arange(r)[None, :], persistent=False)
+            # rank block of every lora_B row (rows are ordered part by part): row i multiplies after_A[:, _cols[i]]
+            block = torch.cat([torch.full((n,), j) for j, n in enumerate(self.qkv_shapes)])
+            self.register_buffer("_ind", torch.cat(cols), persistent=False)
+            self.register_buffer("_cols", block[:, None] * r + torch.arange(r)[None, :], persistent=False)
             self.reset_parameters()
 
     def zero_pad(self, x: torch.Tensor) -> torch.Tensor:
-        """Scatter the enabled parts' columns into the full interleaved QKV width (lora.py:281-342)."""
+        """Place the enabled parts' columns at their positions in the full interleaved QKV width, zeros elsewhere
+        (lora.py:281-342).  Activations (..., sum(qkv_shapes)) are widened along the last dimension; the 2-d product
+        B A of get_lora_AB (sum(qkv_shapes), in_features) along its first (it becomes the weight update's rows)."""
         if all(self.enable_lora):
             return x
-        x = x.transpose(0, 1)
-        result = x.new_zeros((*x.shape[:-1], self.linear.out_features))
-        result = result.view(-1, self.linear.out_features)
-        result = result.index_copy(1, self._ind.to(result.device), x.reshape(-1, sum(self.qkv_shapes)))
-        return result.view((*x.shape[:-1], self.linear.out_features)).transpose(0, 1)
+        dim = 0 if x.dim() == 2 else x.dim() - 1
+        shape = list(x.shape)
+        shape[dim] = self.linear.out_features
+        return x.new_zeros(shape).index_copy_(dim, self._ind.to(x.device), x)
 
     def conv1d(self, input: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-        """Grouped 1x1 convolution == block-diagonal matmul over the enabled parts (lora.py:344-377)."""
-        if self.n_head == self.n_query_groups:
-            return F.conv1d(input, weight, groups=sum(self.enable_lora))
-        input_splitted = input.chunk(sum(self.enable_lora), dim=1)
-        weight_splitted = weight.split(self.qkv_shapes)
-        return torch.cat([F.conv1d(a, b) for a, b in zip(input_splitted, weight_splitted)], dim=1)
+        """Channels-first block-diagonal product (lora.py:344-377): input (B, r n_enabled, T), weight (sum(qkv_shapes), r, 1)
+        -> (B, sum(qkv_shapes), T); part j's rows of `weight` see only rank block j of `input`."""
+        w = weight.squeeze(-1)
+        out, row = [], 0
+        for j, n in enumerate(self.qkv_shapes):
+            out.append(torch.matmul(w[row:row + n], input[:, j * self.r:(j + 1) * self.r]))
+            row += n
+        return torch.cat(out, dim=1)
 
     def get_lora_AB(self) -> torch.Tensor:
         lora = self.conv1d(self.lora_A.data.unsqueeze(0), self.lora_B.data.unsqueeze(-1)).squeeze(0)

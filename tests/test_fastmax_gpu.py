@@ -430,6 +430,97 @@ def test_full_baseline_shape_properties():
     assert not torch.equal(o4[:, :, t:], o[:, :, t:])
 
 
+def test_config4_full_size_second_order_d128():
+    """BASELINE config 4 head shape at its full length: fastmax(p=2) -- what lit_gpt/model.py:485 calls -- on
+    (2,32,4096,128) bf16, forward + backward.  Sampled heads against the dense fp64 known-answer form of the
+    oracle (fastmax.py:336-381 + 103 and its derivative) on the upcast inputs, plus size-independent properties:
+    rows of the implied attention matrix sum to one, causality bit for bit (outputs, and nothing upstream of a
+    gradient cut-off moves), gradient of a constant-one value tensor sums to zero in q and k."""
+    from attention_mechanisms.fastmax import fastmax
+    from oracle import fastmax_oracle as orc
+    B, H, N, D = 2, 32, 4096, 128
+    g = torch.Generator(device="cuda").manual_seed(4)
+    q, k, v, go = (torch.randn(B, H, N, D, device="cuda", generator=g).to(torch.bfloat16) for _ in range(4))
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    o = fastmax(q, k, v, mask=True, p=2)
+    assert o.shape == (B, H, N, D) and o.dtype == torch.bfloat16 and o.is_contiguous()
+    o.backward(go)
+    for (b, h) in ((0, 0), (1, 31)):
+        qn, kn, vn, gn = (t[b:b + 1, h:h + 1].detach().float().cpu().numpy() for t in (q, k, v, go))
+        ro, _ = orc.fastmax_fwd_dense(qn, kn, vn, mask=True, p=2)
+        assert rel_err(o[b:b + 1, h:h + 1].detach().float().cpu().numpy(), ro) < 8e-3
+        for t, r, n in zip((q, k, v), orc.fastmax_bwd_dense(qn, kn, vn, gn, mask=True, p=2), "qkv"):
+            assert rel_err(t.grad[b:b + 1, h:h + 1].float().cpu().numpy(), r) < 2.5e-2, n
+    with torch.no_grad():
+        ones = fastmax(q, k, torch.ones_like(v), mask=True, p=2)
+        assert float((ones.float() - 1).abs().max()) < 8e-3                     # one bf16 rounding of 1 +- eps
+        t = 2049
+        q2, k2, v2 = q.detach().clone(), k.detach().clone(), v.detach().clone()
+        q2[:, :, t:], k2[:, :, t:], v2[:, :, t:] = 1.5, -0.5, 3.0
+        o2 = fastmax(q2, k2, v2, mask=True, p=2)
+        assert torch.equal(o2[:, :, :t], o.detach()[:, :, :t]) and not torch.equal(o2[:, :, t:], o.detach()[:, :, t:])
+    # a gradient that is zero from token t on leaves dK, dV of the tokens >= t exactly zero (nothing attends backwards)
+    go2 = go.clone()
+    go2[:, :, t:] = 0
+    qq, kk, vv = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    fastmax(qq, kk, vv, mask=True, p=2).backward(go2)
+    assert float(kk.grad[:, :, t:].abs().max()) == 0 and float(vv.grad[:, :, t:].abs().max()) == 0
+    assert float(qq.grad[:, :, t:].abs().max()) == 0 and float(qq.grad[:, :, :t].abs().max()) > 0
+
+
+def _prologue_backward_fp64(x, gy):
+    """d/dx of y = (x - mean_D x) / max_n ||x_n - mean_D x_n|| (fastmax.py:326-334), one head (N,D), fp64: the chain rule
+    through the oracle's normalize -- only the row that attains the max-norm carries the dL/dM term."""
+    xc = x - x.mean(-1, keepdims=True)
+    nrm = np.sqrt((xc * xc).sum(-1))
+    ns = int(nrm.argmax())
+    M = nrm[ns]
+    gxc = gy / M
+    gxc[ns] -= (gy * xc).sum() / (M * M) * xc[ns] / M
+    return gxc - gxc.mean(-1, keepdims=True)
+
+
+def test_config5_full_size_linearmax_16k():
+    """BASELINE config 5 at its full length: fastmax_hack (linearmax, fastmax_hack.py:36-60) on (1,32,16384,128) bf16,
+    forward + backward (the O(N) causal scan over 256 chunks, sequence split included).  Sampled heads against the C
+    oracle (prologue + first-order scan with nt=1, and the chain rule through the prologue for dq, dk) on the upcast
+    inputs, plus rows-sum-to-one and bit-exact causality."""
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    from oracle import c_oracle, fastmax_oracle as orc
+    B, H, N, D = 1, 32, 16384, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q, k, v, go = (torch.randn(B, H, N, D, device="cuda", generator=g).to(torch.bfloat16) for _ in range(4))
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    o = fastmax_hack(q, k, v, p=1, mask=True)
+    assert o.shape == (B, H, N, D) and o.dtype == torch.bfloat16
+    o.backward(go)
+    for h in (0, 17, 31):
+        qn, kn, vn, gn = (t[:, h:h + 1].detach().float().cpu().numpy() for t in (q, k, v, go))
+        qq, kk = orc.normalize_qk(qn, kn)
+        qq32, kk32 = qq.astype(np.float32), kk.astype(np.float32)              # what the C oracle takes
+        ro, _ = c_oracle.fwd(qq32, kk32, vn, mask=True, nt=1.0, p=1)
+        assert rel_err(o[:, h:h + 1].detach().float().cpu().numpy(), ro) < 8e-3, h
+        dqn, dkn, dv = c_oracle.bwd(qq32, kk32, vn, gn, mask=True, nt=1.0, p=1)
+        dq = _prologue_backward_fp64(qn[0, 0].astype(np.float64), np.asarray(dqn, dtype=np.float64)[0, 0])
+        dk = _prologue_backward_fp64(kn[0, 0].astype(np.float64), np.asarray(dkn, dtype=np.float64)[0, 0])
+        assert rel_err(v.grad[0, h].float().cpu().numpy(), dv[0, 0]) < 2.5e-2, h
+        assert rel_err(q.grad[0, h].float().cpu().numpy(), dq) < 2.5e-2, h
+        assert rel_err(k.grad[0, h].float().cpu().numpy(), dk) < 2.5e-2, h
+    with torch.no_grad():
+        ones = fastmax_hack(q, k, torch.ones_like(v), p=1, mask=True)
+        assert float((ones.float() - 1).abs().max()) < 8e-3
+        # causality: V of the tokens >= t does not reach outputs < t (q, k are left alone: the prologue's max-norm is global)
+        t = 8193
+        # (both sides without autograd: the inference route fuses the prologue into the scan kernel and keeps the
+        # normalised q, k in fp32, the training route rounds them to bf16 -- not the same bits)
+        o1 = fastmax_hack(q, k, v, p=1, mask=True)
+        assert rel_err(o1.float().cpu().numpy(), o.detach().float().cpu().numpy()) < 8e-3
+        v2 = v.detach().clone()
+        v2[:, :, t:] = 3.0
+        o2 = fastmax_hack(q, k, v2, p=1, mask=True)
+        assert torch.equal(o2[:, :, :t], o1[:, :, :t]) and not torch.equal(o2[:, :, t:], o1[:, :, t:])
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("B,H,T,D", [(2, 3, 200, 64), (1, 2, 70, 32), (1, 2, 130, 128)])
 def test_decode_state_cache_matches_masked_forward(B, H, T, D, dt, tol):

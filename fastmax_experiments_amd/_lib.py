@@ -26,7 +26,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_lora_down", "fastmax_hip_lora_tn_workspace", "fastmax_hip_lora_tn", "fastmax_hip_lora_up",
            "fastmax_hip_forward_state_bytes", "fastmax_hip_backward_with_states",
            "fastmax_hip_lora_scatter", "fastmax_hip_lora_scatter_backward",
-           "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand"]
+           "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand", "fastmax_hip_tune"]
 
 
 class Problem(ctypes.Structure):
@@ -53,6 +53,8 @@ def lib():
             raise RuntimeError(f"libfastmax_hip.so does not export {s}")
     vp, i64p, fp, sz, ci = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     pp = ctypes.POINTER(Problem)
+    L.fastmax_hip_tune.argtypes = [ctypes.c_char_p, ci]
+    L.fastmax_hip_tune.restype = ci
     L.fastmax_hip_forward_workspace.argtypes = [pp]
     L.fastmax_hip_forward_workspace.restype = sz
     L.fastmax_hip_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, sz, vp]
@@ -122,7 +124,7 @@ def lib():
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 3:
+    if L.fastmax_hip_abi_version() != 4:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

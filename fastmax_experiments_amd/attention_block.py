@@ -48,7 +48,7 @@ class CausalSelfAttention(nn.Module):
         if attn_alg not in ("fastmax", "linearmax"):
             raise ValueError(f"Attention algorithm {attn_alg} not supported")          # model.py:450-451
         self.attn_alg = attn_alg
-        self.fused_neighbours = True          # False: the reference's tensor-op sequence (kept for parity tests)
+        self.fused_neighbours = True          # False: tensor-op slicing instead of the one-pass HIP kernel (A/B, parity tests)
         shape = (n_head + 2 * self.n_query_groups) * self.head_size
         self.attn = LoRAQKVLinear(n_embd, shape, n_head=n_head, n_query_groups=self.n_query_groups, r=r, lora_alpha=alpha,
                                   lora_dropout=dropout, enable_lora=(to_query, to_key, to_value), bias=bias)
@@ -84,18 +84,15 @@ class CausalSelfAttention(nn.Module):
             q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
                                              self.rope_n_elem)
         else:
-            qkv = qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size).permute(0, 2, 3, 1, 4)
-            q, k, v = qkv.split((q_per_kv, 1, 1), dim=2)
-            if self.n_query_groups != self.n_head and (input_pos is None or self.n_query_groups != 1):
-                k = k.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
-                v = v.expand(B, self.n_query_groups, q_per_kv, T, self.head_size)
-            q = q.reshape(B, -1, T, self.head_size)
-            k = k.reshape(B, -1, T, self.head_size)
-            v = v.reshape(B, -1, T, self.head_size)
-            q_roped = apply_rope(q[..., :self.rope_n_elem], cos, sin)
-            k_roped = apply_rope(k[..., :self.rope_n_elem], cos, sin)
-            q = torch.cat((q_roped, q[..., self.rope_n_elem:]), dim=-1)
-            k = torch.cat((k_roped, k[..., self.rope_n_elem:]), dim=-1)
+            # shapes the one-pass kernel does not take (decode with input_pos, rotary widths that are not whole 16-byte
+            # pieces): plain slicing of the (B, T, group, slot, hs) view -- slots 0..q_per_kv-1 are the group's query heads,
+            # then its key head, then its value head (model.py:397-420) -- with K, V repeated per query head
+            qkv5 = qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size)
+            q = qkv5[:, :, :, :q_per_kv].permute(0, 2, 3, 1, 4).reshape(B, self.n_head, T, self.head_size)
+            k, v = (qkv5[:, :, :, q_per_kv + i].permute(0, 2, 1, 3).repeat_interleave(q_per_kv, dim=1) for i in (0, 1))
+            n = self.rope_n_elem
+            q = torch.cat((apply_rope(q[..., :n], cos, sin), q[..., n:]), dim=-1)
+            k = torch.cat((apply_rope(k[..., :n], cos, sin), k[..., n:]), dim=-1)
         mask = input_pos is None                                   # model.py:462-466, 477-481
         if self.attn_alg == "linearmax":
             y = fastmax_hack(q, k, v, p=1, mask=mask)              # model.py:472

@@ -2,15 +2,14 @@
 #include "fastmax_common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 using namespace fastmax;
 
 namespace {
-// bf16 problems take the all-MFMA kernel; FASTMAX_BF16_KERNEL=gen keeps the generic one (A/B runs)
+// bf16 problems take the all-MFMA kernel; FASTMAX_BF16_KERNEL=gen (tuning key "bf16_kernel" = 0) keeps the generic one
 bool use_bf16_kernel(const fastmax_problem& p) {
-    if (!mfma_bf16_supported(p)) return false;
-    const char* e = getenv("FASTMAX_BF16_KERNEL");
-    return !(e && e[0] == 'g');
+    return mfma_bf16_supported(p) && tune_get(TUNE_BF16_KERNEL) != 0;
 }
 int validate(const fastmax_problem* p) {
     if (!p) return FASTMAX_E_NULL;
@@ -47,9 +46,42 @@ bool aligned16(const void* ptr, const int64_t* s, int dtype) {
 }
 }  // namespace
 
+namespace fastmax {
+namespace {
+struct TuneEntry { const char* name; const char* env; int value; };
+TuneEntry g_tune[TUNE_COUNT] = {
+    {"mfma_variant", "FASTMAX_MFMA_VARIANT", 200},    // headline forward kernel: 200 = second generation (fastmax_mfma_v2.hip)
+    {"bf16_kernel", "FASTMAX_BF16_KERNEL", 1},
+};
+bool g_tune_loaded = false;
+void tune_load() {
+    if (g_tune_loaded) return;
+    for (int i = 0; i < TUNE_COUNT; ++i) {
+        const char* e = getenv(g_tune[i].env);
+        if (!e) continue;
+        if (i == TUNE_BF16_KERNEL) g_tune[i].value = e[0] == 'g' ? 0 : 1;
+        else g_tune[i].value = atoi(e);
+    }
+    g_tune_loaded = true;
+}
+}  // namespace
+int tune_get(int key) {
+    tune_load();
+    return g_tune[key].value;
+}
+int tune_set(const char* name, int value) {
+    tune_load();
+    for (int i = 0; i < TUNE_COUNT; ++i)
+        if (!strcmp(name, g_tune[i].name)) { g_tune[i].value = value; return FASTMAX_OK; }
+    return FASTMAX_E_BAD_SHAPE;
+}
+}  // namespace fastmax
+
 extern "C" {
 
 int fastmax_hip_abi_version(void) { return FASTMAX_ABI_VERSION; }
+
+int fastmax_hip_tune(const char* name, int value) { return name ? tune_set(name, value) : FASTMAX_E_NULL; }
 
 const char* fastmax_hip_error_string(int code) {
     switch (code) {

@@ -474,9 +474,11 @@ static int launch_variant(const MfmaParams& prm, int nblocks, hipStream_t stream
 
 int launch_fwd_mfma_p1(const FwdArgs& a) {
     if (!mfma_p1_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
-    // FASTMAX_MFMA_VARIANT = <prefetch distance 1|2><staged stores 0|1>, tuning knob for A/B runs
-    const char* env = getenv("FASTMAX_MFMA_VARIANT");
-    const int variant = env ? atoi(env) : 121;
+    // tuning key "mfma_variant" (FASTMAX_MFMA_VARIANT at load): 200 = second-generation kernel (fastmax_mfma_v2.hip), 209 its
+    // memory-only ablation; 1xx / 2xx = this file's <prefetch distance><staged stores><schedule> variants, for A/B runs
+    const int variant = tune_get(TUNE_MFMA_VARIANT);
+    if (variant >= 200 && variant <= 209 && mfma_p1_v2_supported(a))
+        return launch_fwd_mfma_p1_v2(a, variant == 209 ? 1 : variant - 200);      // 201 / 202 / 203: A/B forms, see there
     const SplitPlan plan = split_plan(a.prob);
     if (plan.nseg > 1) {
         if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, 64)) return FASTMAX_E_WORKSPACE;

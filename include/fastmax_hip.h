@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 3   /* 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 4   /* 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -53,6 +53,12 @@ enum fastmax_path {
     FASTMAX_PATH_MFMA = 3,       /* p=1 masked, chunked scan on the matrix cores (split-bf16), linear in N */
     FASTMAX_PATH_QUADRATIC_MFMA = 4 /* f(QK^T)V tiles on the matrix cores: p=2, unmasked, N_q != N_k */
 };
+
+/* Run-time tuning knob for A/B runs and ablations (no reference counterpart).  The FASTMAX_* environment variables are read
+ * once, at the first call into the library; afterwards a knob changes only through this call.  Keys: "mfma_variant" (headline
+ * forward kernel generation / schedule), "bf16_kernel" (1 = all-MFMA bf16 scan, 0 = generic).  Host-only, not stream-ordered:
+ * call it between launches.  Returns 0, or FASTMAX_E_BAD_SHAPE for an unknown key. */
+int fastmax_hip_tune(const char* name, int value);
 
 typedef struct fastmax_problem {
     int B, H, Nq, Nk, D;

@@ -10,6 +10,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from attention_mechanisms.fastmax import fastmax
+from fastmax_experiments_amd import _lib
+
+TUNE_KEYS = {"FASTMAX_MFMA_VARIANT": b"mfma_variant"}
+
+
+def set_variant(var, x):
+    """library knobs are read from the environment once; afterwards they change through fastmax_hip_tune"""
+    if var in TUNE_KEYS:
+        _lib.check(_lib.lib().fastmax_hip_tune(TUNE_KEYS[var], int(x)), "fastmax_hip_tune")
+    else:
+        os.environ[var] = x
 
 
 def main():
@@ -31,7 +42,7 @@ def main():
     res = {x: [] for x in vals}
     for rd in range(rounds + 1):
         for x in vals:
-            os.environ[var] = x
+            set_variant(var, x)
             o = fastmax(q, k, v)
             if ref is None:
                 ref = o.clone()

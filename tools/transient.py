@@ -11,6 +11,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from attention_mechanisms.fastmax import fastmax
+from fastmax_experiments_amd import _lib
+
+TUNE_KEYS = {"FASTMAX_MFMA_VARIANT": b"mfma_variant"}
+
+
+def set_variant(var, x):
+    """library knobs are read from the environment once; afterwards they change through fastmax_hip_tune"""
+    if var in TUNE_KEYS:
+        _lib.check(_lib.lib().fastmax_hip_tune(TUNE_KEYS[var], int(x)), "fastmax_hip_tune")
+    else:
+        os.environ[var] = x
 
 
 def main():
@@ -30,12 +41,12 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     q, k, v = (torch.randn(*shape, device="cuda", generator=g) for _ in range(3))
     for x in vals:                                   # compile / attribute-set / allocator warm: one launch each, then idle
-        os.environ[var] = x
+        set_variant(var, x)
         fastmax(q, k, v)
     torch.cuda.synchronize()
     for rp in range(repeat):
         for x in vals:
-            os.environ[var] = x
+            set_variant(var, x)
             time.sleep(idle)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
             ev[0].record()

@@ -26,7 +26,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_lora_down", "fastmax_hip_lora_tn_workspace", "fastmax_hip_lora_tn", "fastmax_hip_lora_up",
            "fastmax_hip_forward_state_bytes", "fastmax_hip_backward_with_states",
            "fastmax_hip_lora_scatter", "fastmax_hip_lora_scatter_backward",
-           "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand", "fastmax_hip_tune"]
+           "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand", "fastmax_hip_tune",
+           "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s"]
 
 
 class Problem(ctypes.Structure):
@@ -103,6 +104,12 @@ def lib():
     L.fastmax_hip_nf4_linear_backward_input.restype = ci
     L.fastmax_hip_nf4_dequantize.argtypes = [vp, vp, vp, i64, ci, vp]
     L.fastmax_hip_nf4_dequantize.restype = ci
+    L.fastmax_hip_nf4_linear_forward_s.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, vp]
+    L.fastmax_hip_nf4_linear_forward_s.restype = ci
+    L.fastmax_hip_nf4_linear_backward_input_s.argtypes = [vp, i64, vp, vp, vp, i64, ci, ci, ci, ci, vp]
+    L.fastmax_hip_nf4_linear_backward_input_s.restype = ci
+    L.fastmax_hip_nf4_dequantize_s.argtypes = [vp, vp, vp, i64, ci, vp]
+    L.fastmax_hip_nf4_dequantize_s.restype = ci
     L.fastmax_hip_lora_down.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, ci, vp]
     L.fastmax_hip_lora_down.restype = ci
     L.fastmax_hip_lora_tn_workspace.argtypes = [ci, ci, ci]
@@ -124,7 +131,7 @@ def lib():
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 4:
+    if L.fastmax_hip_abi_version() != 5:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

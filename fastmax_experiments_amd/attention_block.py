@@ -55,10 +55,11 @@ class CausalSelfAttention(nn.Module):
         self.proj = LoRALinear(self.head_size * n_head, n_embd, r=(r if to_projection else 0), lora_alpha=alpha,
                                lora_dropout=dropout, bias=bias)
 
-    def quantize_base(self):
-        """QLoRA: both frozen linears become 4-bit NF4 (what the bnb precision plugin does in the reference)."""
-        self.attn.quantize_base()
-        self.proj.quantize_base()
+    def quantize_base(self, double_quant: bool = False):
+        """QLoRA: both frozen linears become 4-bit NF4 (what the bnb precision plugin does in the reference);
+        ``double_quant`` = the "bnb.nf4-dq" mode (finetune/lora.py:38)."""
+        self.attn.quantize_base(double_quant)
+        self.proj.quantize_base(double_quant)
         return self
 
     def forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, input_pos=None) -> torch.Tensor:

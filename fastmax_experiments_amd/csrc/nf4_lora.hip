@@ -33,10 +33,24 @@ __constant__ float kNF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f
                                0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f,
                                0.7229568362236023f, 1.0f};
 
+// Block scales of the NF4 weight: plain (fp32 absmax per 64 weights) or double-quantised ("nf4-dq": the absmax vector is
+// itself stored as 8-bit codes of a 256-entry map, one fp32 scale per 256 of them, plus one offset -- QLoRA section 3,
+// finetune/lora.py:38 lists the mode).  One scale per 64 weights is decoded where the plain path loads a float.
+struct Nf4Scale {
+    const float* absmax;      // plain: one per 64 consecutive weights (q == nullptr)
+    const uint8_t* q;         // dq: 8-bit code of (absmax - offset) per 64 weights
+    const float* absmax2;     // dq: scale per 256 codes
+    const float* code2;       // dq: 256-entry map
+    float offset;
+    __device__ __forceinline__ float operator[](int64_t blk) const {
+        return q ? fmaf(code2[q[blk]], absmax2[blk >> 8], offset) : absmax[blk];
+    }
+};
+
 struct Nf4Params {
     const void* x;            // fwd: x [M][K]   bwd: dy [M][N]     (bf16 or f32, row-major, ld = ldx)
     const uint8_t* wq;        // packed NF4 codes of W [N][K], row-major, 2 codes / byte
-    const float* absmax;      // one per 64 consecutive weights
+    Nf4Scale absmax;          // block scale of every 64 consecutive weights
     const float* bias;        // [N] or null (fwd only)
     const __bf16* ea;         // [M][32] or null (fwd only)
     const __bf16* eb;         // [N][32] or null
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void nf4_gemv_kernel(Nf4Params prm) {
 
 // ---- dequantise to a dense matrix: the merge path (lora.py:142-168) and the large-M route of the QLoRA linear, where
 // the W tile would otherwise be re-decoded by every one of the M/128 workgroup rows: decode once, then a plain GEMM.
-__global__ __launch_bounds__(256) void nf4_dequant_bf16_vec_kernel(const uint8_t* wq, const float* absmax, __bf16* out, int64_t n8) {
+__global__ __launch_bounds__(256) void nf4_dequant_bf16_vec_kernel(const uint8_t* wq, const Nf4Scale absmax, __bf16* out, int64_t n8) {
     // one thread = 4 packed bytes = 8 weights = one 16-byte store: consecutive lanes read consecutive words and write
     // consecutive 16-byte pieces (the earlier 32-weights-per-thread form wrote 64-byte-strided pieces: 40 us for 16.7 M weights)
     __shared__ float lut[16];
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(256) void nf4_dequant_bf16_vec_kernel(const uint8_t
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_t*>(out) + i);
 }
 template <typename T>
-__global__ void nf4_dequant_kernel(const uint8_t* wq, const float* absmax, T* out, int64_t n) {
+__global__ void nf4_dequant_kernel(const uint8_t* wq, const Nf4Scale absmax, T* out, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
     const unsigned int byte = wq[i >> 1];
@@ -415,17 +429,27 @@ using namespace fastmax;
 
 extern "C" {
 
-int fastmax_hip_nf4_linear_forward(const void* x, int64_t ldx, const uint8_t* wq, const float* absmax, const float* bias,
-                                   const void* ea, const void* eb, void* y, int64_t ldy, int M, int N, int K, int dtype,
-                                   void* stream) {
-    if (!x || !wq || !absmax || !y) return FASTMAX_E_NULL;
+static Nf4Scale to_scale(const fastmax_nf4_scales* sc) {
+    return Nf4Scale{sc->absmax, sc->absmax_q, sc->absmax2, sc->code2, sc->offset};
+}
+static int check_scale(const fastmax_nf4_scales* sc) {
+    if (!sc) return FASTMAX_E_NULL;
+    if (sc->absmax_q) return (sc->absmax2 && sc->code2) ? FASTMAX_OK : FASTMAX_E_NULL;
+    return sc->absmax ? FASTMAX_OK : FASTMAX_E_NULL;
+}
+
+int fastmax_hip_nf4_linear_forward_s(const void* x, int64_t ldx, const uint8_t* wq, const fastmax_nf4_scales* scales,
+                                     const float* bias, const void* ea, const void* eb, void* y, int64_t ldy, int M, int N,
+                                     int K, int dtype, void* stream) {
+    if (!x || !wq || !y) return FASTMAX_E_NULL;
+    if (int rc = check_scale(scales)) return rc;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || (N % 4)) return FASTMAX_E_BAD_SHAPE;
     if ((ea == nullptr) != (eb == nullptr)) return FASTMAX_E_NULL;
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || ((ldx * es) & 15) ||
         ((ldy * es) & 15) || (reinterpret_cast<uintptr_t>(wq) & 15))
         return FASTMAX_E_ALIGNMENT;
-    Nf4Params p{x, wq, absmax, bias, reinterpret_cast<const __bf16*>(ea), reinterpret_cast<const __bf16*>(eb), y, M, N, K,
+    Nf4Params p{x, wq, to_scale(scales), bias, reinterpret_cast<const __bf16*>(ea), reinterpret_cast<const __bf16*>(eb), y, M, N, K,
                 ldx, ldy};
     dim3 grid((N + 127) / 128, (M + 127) / 128), block(256);
     if (M <= 16 && (K % 128) == 0 && (N % 16) == 0 && (!bias || !(reinterpret_cast<uintptr_t>(bias) & 15)) &&
@@ -442,15 +466,16 @@ int fastmax_hip_nf4_linear_forward(const void* x, int64_t ldx, const uint8_t* wq
     return (int)hipGetLastError();
 }
 
-int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const uint8_t* wq, const float* absmax, void* dx,
-                                          int64_t lddx, int M, int N, int K, int dtype, void* stream) {
-    if (!dy || !wq || !absmax || !dx) return FASTMAX_E_NULL;
+int fastmax_hip_nf4_linear_backward_input_s(const void* dy, int64_t lddy, const uint8_t* wq, const fastmax_nf4_scales* scales,
+                                            void* dx, int64_t lddx, int M, int N, int K, int dtype, void* stream) {
+    if (!dy || !wq || !dx) return FASTMAX_E_NULL;
+    if (int rc = check_scale(scales)) return rc;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 128) || (N % 64)) return FASTMAX_E_BAD_SHAPE;
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
     if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15) || ((lddy * es) & 15) ||
         ((lddx * es) & 15) || (reinterpret_cast<uintptr_t>(wq) & 15))
         return FASTMAX_E_ALIGNMENT;
-    Nf4Params p{dy, wq, absmax, nullptr, nullptr, nullptr, dx, M, N, K, lddy, lddx};
+    Nf4Params p{dy, wq, to_scale(scales), nullptr, nullptr, nullptr, dx, M, N, K, lddy, lddx};
     dim3 grid(K / 128, (M + 127) / 128), block(256);
     if (dtype == FASTMAX_BF16) hipLaunchKernelGGL(nf4_linear_dx_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, p);
     else if (dtype == FASTMAX_F32) hipLaunchKernelGGL(nf4_linear_dx_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
@@ -458,21 +483,40 @@ int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const ui
     return (int)hipGetLastError();
 }
 
-int fastmax_hip_nf4_dequantize(const uint8_t* wq, const float* absmax, void* out, int64_t n, int dtype, void* stream) {
-    if (!wq || !absmax || !out) return FASTMAX_E_NULL;
+int fastmax_hip_nf4_dequantize_s(const uint8_t* wq, const fastmax_nf4_scales* scales, void* out, int64_t n, int dtype, void* stream) {
+    if (!wq || !out) return FASTMAX_E_NULL;
+    if (int rc = check_scale(scales)) return rc;
     if (n <= 0 || (n % 64)) return FASTMAX_E_BAD_SHAPE;
+    const Nf4Scale sc = to_scale(scales);
     const int64_t threads = (n + 1) / 2;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     if (dtype == FASTMAX_BF16 && !((reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(out)) & 15)) {
         const int64_t n8 = n / 8;
         hipLaunchKernelGGL(nf4_dequant_bf16_vec_kernel, dim3((unsigned)((n8 + 255) / 256)), block, 0, (hipStream_t)stream, wq,
-                           absmax, (__bf16*)out, n8);
+                           sc, (__bf16*)out, n8);
     } else if (dtype == FASTMAX_BF16)
-        hipLaunchKernelGGL(nf4_dequant_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, wq, absmax, (__bf16*)out, n);
+        hipLaunchKernelGGL(nf4_dequant_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, wq, sc, (__bf16*)out, n);
     else if (dtype == FASTMAX_F32)
-        hipLaunchKernelGGL(nf4_dequant_kernel<float>, grid, block, 0, (hipStream_t)stream, wq, absmax, (float*)out, n);
+        hipLaunchKernelGGL(nf4_dequant_kernel<float>, grid, block, 0, (hipStream_t)stream, wq, sc, (float*)out, n);
     else return FASTMAX_E_BAD_DTYPE;
     return (int)hipGetLastError();
+}
+
+// plain NF4 (fp32 block scales): the same entry points with the scales given as one pointer
+int fastmax_hip_nf4_linear_forward(const void* x, int64_t ldx, const uint8_t* wq, const float* absmax, const float* bias,
+                                   const void* ea, const void* eb, void* y, int64_t ldy, int M, int N, int K, int dtype,
+                                   void* stream) {
+    const fastmax_nf4_scales sc{absmax, nullptr, nullptr, nullptr, 0.f};
+    return fastmax_hip_nf4_linear_forward_s(x, ldx, wq, &sc, bias, ea, eb, y, ldy, M, N, K, dtype, stream);
+}
+int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const uint8_t* wq, const float* absmax, void* dx,
+                                          int64_t lddx, int M, int N, int K, int dtype, void* stream) {
+    const fastmax_nf4_scales sc{absmax, nullptr, nullptr, nullptr, 0.f};
+    return fastmax_hip_nf4_linear_backward_input_s(dy, lddy, wq, &sc, dx, lddx, M, N, K, dtype, stream);
+}
+int fastmax_hip_nf4_dequantize(const uint8_t* wq, const float* absmax, void* out, int64_t n, int dtype, void* stream) {
+    const fastmax_nf4_scales sc{absmax, nullptr, nullptr, nullptr, 0.f};
+    return fastmax_hip_nf4_dequantize_s(wq, &sc, out, n, dtype, stream);
 }
 
 }  // extern "C"

@@ -115,7 +115,7 @@ class DataParallelStepper:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, train: TrainArgs,
                  loss_fn: Callable[[torch.nn.Module, object], torch.Tensor], scheduler=None, group=None,
-                 bucket_dtype: Optional[torch.dtype] = None):
+                 bucket_dtype: Optional[torch.dtype] = None, time_comm: bool = False):
         self.model, self.optimizer, self.train, self.loss_fn = model, optimizer, train, loss_fn
         self.scheduler, self.group = scheduler, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -123,6 +123,28 @@ class DataParallelStepper:
         self.bucket = FlatGradBucket([p for p in model.parameters() if p.requires_grad], dtype=bucket_dtype)
         self.iter_num = 0
         self.step_count = 0
+        # time_comm: bracket the one collective of every optimizer step (device events on a HIP device, host clock else)
+        self.time_comm = time_comm
+        self.comm_ms: list = []
+
+    def _timed_all_reduce(self):
+        if not self.time_comm:
+            return self.bucket.all_reduce_mean(self.group)
+        if self.bucket.flat.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.bucket.all_reduce_mean(self.group)
+            e1.record()
+            self.comm_ms.append((e0, e1))                 # resolved lazily: no host sync inside the step
+        else:
+            import time
+            t0 = time.perf_counter()
+            self.bucket.all_reduce_mean(self.group)
+            self.comm_ms.append((time.perf_counter() - t0) * 1e3)
+
+    def comm_times_ms(self):
+        """milliseconds of every timed all-reduce so far (synchronises the device events)"""
+        return [t if isinstance(t, float) else t[0].elapsed_time(t[1]) for t in self.comm_ms]
 
     def micro_step(self, batch) -> torch.Tensor:
         """One micro-batch: forward, backward of loss/accum; at the boundary all-reduce + optimizer step.
@@ -132,7 +154,7 @@ class DataParallelStepper:
         loss = self.loss_fn(self.model, batch)
         (loss / self.accum).backward()
         if not is_accumulating:
-            self.bucket.all_reduce_mean(self.group)
+            self._timed_all_reduce()
             if self.train.max_norm is not None:
                 torch.nn.utils.clip_grad_norm_(self.bucket.params, self.train.max_norm)
             self.optimizer.step()

@@ -48,31 +48,118 @@ def nf4_quantize(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return packed.contiguous(), absmax.contiguous()
 
 
-def nf4_dequantize(packed: torch.Tensor, absmax: torch.Tensor, shape, dtype=torch.float32) -> torch.Tensor:
-    """Inverse of nf4_quantize (HIP kernel for device tensors, tensor ops for host tensors)."""
+def nf4_dequantize(packed: torch.Tensor, absmax, shape, dtype=torch.float32) -> torch.Tensor:
+    """Inverse of nf4_quantize (HIP kernel for device tensors, tensor ops for host tensors).  `absmax`: the fp32 block
+    scales, or the weight's whole quant_state list (plain or double-quantised scales)."""
     n = int(torch.Size(shape).numel())
+    qs = absmax if isinstance(absmax, (list, tuple)) else [absmax, None, None, BLOCK, None, "nf4"]
     if packed.device.type == "cuda" and dtype in (torch.float32, torch.bfloat16):
         out = torch.empty(n, dtype=dtype, device=packed.device)
+        sc = NF4Scales(qs)
         with torch.cuda.device(packed.device):
-            rc = _lib.lib().fastmax_hip_nf4_dequantize(packed.data_ptr(), absmax.data_ptr(), out.data_ptr(), n,
-                                                       _lib.F32 if dtype == torch.float32 else _lib.BF16,
-                                                       ctypes.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream))
-        _lib.check(rc, "fastmax_hip_nf4_dequantize")
+            rc = _lib.lib().fastmax_hip_nf4_dequantize_s(packed.data_ptr(), sc.ref, out.data_ptr(), n,
+                                                         _lib.F32 if dtype == torch.float32 else _lib.BF16,
+                                                         ctypes.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream))
+        _lib.check(rc, "fastmax_hip_nf4_dequantize_s")
         return out.view(shape)
     code = NF4_CODE.to(packed.device)
     idx = torch.stack([packed >> 4, packed & 15], dim=1).reshape(-1).long()
-    vals = code[idx].reshape(-1, BLOCK) * absmax[:, None]
+    vals = code[idx].reshape(-1, BLOCK) * block_scales(qs)[:, None]
     return vals.reshape(shape).to(dtype)
+
+
+# ---- double quantisation of the block scales ("bnb.nf4-dq", finetune/lora.py:38) ---------------------------------------
+# QLoRA (arXiv 2305.14314, section 3): the fp32 absmax vector is shifted by its mean and stored as 8-bit codes of a
+# 256-level dynamic map, blockwise with block 256 and one fp32 scale per block: 0.127 bit per weight instead of 0.5.
+# bitsandbytes is absent from the reference tree and this image; the map below restates its publicly documented
+# `create_dynamic_map(signed=True, max_exponent_bits=7, total_bits=8)`: for every decade 10^-6 .. 10^0 the midpoints of
+# 2^i equal sub-intervals of [0.1, 1] (i = 0..6), both signs, plus 0 and 1.  Parity with bitsandbytes: UNPINNED.
+DQ_BLOCK = 256
+
+
+def dynamic_map_8bit() -> torch.Tensor:
+    vals = [0.0, 1.0]
+    for i in range(7):
+        edges = torch.linspace(0.1, 1.0, 2 ** i + 1, dtype=torch.float64)
+        mids = (edges[:-1] + edges[1:]) / 2 * 10.0 ** (i - 6)
+        vals += mids.tolist() + (-mids).tolist()
+    assert len(vals) == 256
+    return torch.tensor(sorted(vals), dtype=torch.float32)
+
+
+def absmax_double_quantize(absmax: torch.Tensor):
+    """fp32 block scales -> (codes uint8 [n], absmax2 fp32 [ceil(n/256)], offset fp32 scalar tensor, code2 fp32 [256])."""
+    a = absmax.detach().float()
+    offset = a.mean()
+    c = a - offset
+    n = c.numel()
+    pad = (-n) % DQ_BLOCK
+    blocks = F.pad(c, (0, pad)).reshape(-1, DQ_BLOCK)
+    absmax2 = blocks.abs().amax(dim=1)
+    code2 = dynamic_map_8bit().to(a.device)
+    scaled = (blocks / absmax2.clamp_min(1e-38)[:, None]).reshape(-1)[:n]
+    # nearest map entry: the map is sorted, so look at the two neighbours of the insertion point
+    hi = torch.searchsorted(code2, scaled).clamp(1, 255)
+    lo = hi - 1
+    codes = torch.where((scaled - code2[lo]).abs() <= (code2[hi] - scaled).abs(), lo, hi).to(torch.uint8)
+    return codes.contiguous(), absmax2.contiguous(), offset.reshape(()), code2
+
+
+def absmax_double_dequantize(codes, absmax2, offset, code2) -> torch.Tensor:
+    idx = torch.arange(codes.numel(), device=codes.device) // DQ_BLOCK
+    return code2[codes.long()] * absmax2[idx] + offset
+
+
+class NF4Scales:
+    """The block scales of one NF4 weight as the C ABI takes them (include/fastmax_hip.h `fastmax_nf4_scales`): plain fp32
+    absmax, or the double-quantised form.  Keeps the tensors alive for as long as the ctypes struct is in use."""
+
+    class _C(ctypes.Structure):
+        _fields_ = [("absmax", ctypes.c_void_p), ("absmax_q", ctypes.c_void_p), ("absmax2", ctypes.c_void_p),
+                    ("code2", ctypes.c_void_p), ("offset", ctypes.c_float)]
+
+    def __init__(self, quant_state):
+        stats = quant_state[4]
+        if stats is None:
+            self.tensors = (quant_state[0],)
+            self.c = self._C(quant_state[0].data_ptr(), None, None, None, 0.0)
+        else:
+            offset, (absmax2, code2) = stats
+            self.tensors = (quant_state[0], absmax2, code2)
+            self.c = self._C(None, quant_state[0].data_ptr(), absmax2.data_ptr(), code2.data_ptr(), float(offset))
+        self.ref = ctypes.byref(self.c)
+
+    @property
+    def device(self):
+        return self.tensors[0].device
+
+
+def block_scales(quant_state) -> torch.Tensor:
+    """fp32 absmax vector of a quant_state, whichever way it is stored (host / device tensor ops)."""
+    if quant_state[4] is None:
+        return quant_state[0]
+    offset, (absmax2, code2) = quant_state[4]
+    return absmax_double_dequantize(quant_state[0], absmax2, offset.to(absmax2.device), code2)
 
 
 class Params4bit(nn.Parameter):
     """Packed NF4 storage that looks like what lora.py:151-161 / utils.py:36-38 touch on a bnb weight:
     ``dtype == torch.uint8`` and ``quant_state`` with the original shape at index 1."""
 
-    def __new__(cls, data, quant_state=None):
+    def __new__(cls, data, requires_grad=False, quant_state=None):
+        # (data, requires_grad) is the call nn.Parameter.__deepcopy__ makes; a list in second place is the old
+        # (data, quant_state) form
+        if isinstance(requires_grad, (list, tuple)):
+            requires_grad, quant_state = False, requires_grad
         self = torch.Tensor._make_subclass(cls, data, False)
         self.quant_state = quant_state
         return self
+
+    def __deepcopy__(self, memo):
+        import copy
+        out = type(self)(self.data.clone(), False, copy.deepcopy(self.quant_state, memo))
+        memo[id(self)] = out
+        return out
 
 
 class NF4Linear(nn.Module):
@@ -82,23 +169,33 @@ class NF4Linear(nn.Module):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
         n = in_features * out_features
-        self.weight = Params4bit(torch.zeros(n // 2, dtype=torch.uint8, device=device),
+        self.weight = Params4bit(torch.zeros(n // 2, dtype=torch.uint8, device=device), False,
                                  [torch.ones(n // BLOCK, dtype=torch.float32, device=device),
                                   torch.Size((out_features, in_features)), dtype or torch.bfloat16, BLOCK, None, "nf4"])
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=torch.float32, device=device),
                                  requires_grad=False) if bias else None
 
     @classmethod
-    def from_linear(cls, lin: nn.Linear) -> "NF4Linear":
+    def from_linear(cls, lin: nn.Linear, double_quant: bool = False) -> "NF4Linear":
         q = cls(lin.in_features, lin.out_features, bias=lin.bias is not None, device=lin.weight.device,
                 dtype=lin.weight.dtype)
-        q.load_dense(lin.weight.data, None if lin.bias is None else lin.bias.data)
+        q.load_dense(lin.weight.data, None if lin.bias is None else lin.bias.data, double_quant=double_quant)
         return q
 
-    def load_dense(self, w: torch.Tensor, bias=None):
+    @property
+    def double_quant(self) -> bool:
+        return self.weight.quant_state[4] is not None
+
+    def load_dense(self, w: torch.Tensor, bias=None, double_quant=None):
+        """(re)quantise from a dense weight; ``double_quant`` None keeps the layer's current mode ("bnb.nf4" / "bnb.nf4-dq")"""
+        if double_quant is None:
+            double_quant = self.weight.quant_state is not None and self.weight.quant_state[4] is not None
         packed, absmax = nf4_quantize(w)
         qs = [absmax, torch.Size(w.shape), w.dtype, BLOCK, None, "nf4"]
-        self.weight = Params4bit(packed, qs)
+        if double_quant:
+            codes, absmax2, offset, code2 = absmax_double_quantize(absmax)
+            qs[0], qs[4] = codes, [offset, [absmax2, code2]]
+        self.weight = Params4bit(packed, False, qs)
         self._dense_cache = None
         if bias is not None:
             self.bias = nn.Parameter(bias.detach().float().clone(), requires_grad=False)
@@ -107,15 +204,28 @@ class NF4Linear(nn.Module):
         super()._apply(fn, recurse)
         self._dense_cache = None                                                          # re-enable after moving the module
         qs = self.weight.quant_state
-        moved = fn(qs[0])
-        qs[0] = moved if moved.dtype == torch.float32 else qs[0].to(moved.device)       # absmax stays fp32
+        dev = fn(torch.empty(0, device=qs[0].device)).device                              # where `fn` sends things
+        qs[0] = qs[0].to(dev)                                                             # scales keep their dtypes (fp32 / uint8)
+        if qs[4] is not None:
+            offset, (absmax2, code2) = qs[4]
+            qs[4] = [offset.to(dev), [absmax2.to(dev), code2.to(dev)]]
         if self.weight.dtype != torch.uint8:                                              # .to(dtype) must not touch codes
             raise RuntimeError("NF4 codes were cast; move NF4Linear with .to(device) only")
         self.weight.quant_state = qs
         return self
 
+    def __deepcopy__(self, memo):
+        import copy
+        out = copy.copy(self)                                   # shallow first: then every mutable member is replaced
+        memo[id(self)] = out
+        out._parameters = {k: copy.deepcopy(v, memo) for k, v in self._parameters.items()}
+        out._buffers = {k: copy.deepcopy(v, memo) for k, v in self._buffers.items()}
+        out._modules = {}
+        out._dense_cache = None                                 # never share the decoded copy of the original
+        return out
+
     def dequantize(self, dtype=torch.float32) -> torch.Tensor:
-        return nf4_dequantize(self.weight.data, self.weight.quant_state[0], self.weight.quant_state[1], dtype)
+        return nf4_dequantize(self.weight.data, self.weight.quant_state, self.weight.quant_state[1], dtype)
 
     # Opt-in, MI355X-specific: keep a decoded bf16 copy of the frozen weight next to the 4-bit codes.  288 GB of HBM hold
     # the bf16 copies of a 7B model (14 GB) with room to spare; the checkpoint and the optimizer state stay 4-bit / LoRA-only,
@@ -130,13 +240,21 @@ class NF4Linear(nn.Module):
     # the block scales travel with the module state (state_dict round trips of a quantised model)
     def get_extra_state(self):
         qs = self.weight.quant_state
-        return {"absmax": qs[0].detach().cpu(), "shape": tuple(qs[1]), "blocksize": qs[3], "quant_type": qs[5]}
+        st = {"absmax": qs[0].detach().cpu(), "shape": tuple(qs[1]), "blocksize": qs[3], "quant_type": qs[5]}
+        if qs[4] is not None:
+            offset, (absmax2, code2) = qs[4]
+            st["double_quant"] = {"offset": offset.detach().cpu(), "absmax2": absmax2.detach().cpu(), "code2": code2.detach().cpu()}
+        return st
 
     def set_extra_state(self, state):
         qs = self.weight.quant_state
-        qs[0] = state["absmax"].to(self.weight.device)
+        dev = self.weight.device
+        qs[0] = state["absmax"].to(dev)
         qs[1] = torch.Size(state["shape"])
+        dq = state.get("double_quant")
+        qs[4] = None if dq is None else [dq["offset"].to(dev), [dq["absmax2"].to(dev), dq["code2"].to(dev)]]
         self.weight.quant_state = qs
+        self._dense_cache = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return qlora_linear(x, self, None, None)
@@ -157,17 +275,18 @@ DENSE_M = int(os.environ.get("FASTMAX_NF4_DENSE_M", "2048"))
 _dense_scratch = {}
 
 
-def _dense_weight(wq, absmax, N, K):
-    """bf16 (N, K) view of a per-device scratch buffer holding the decoded weight (valid until the next call on the stream)."""
-    key = wq.device
+def _dense_weight(wq, scales, N, K):
+    """bf16 (N, K) view of a scratch buffer holding the decoded weight.  One buffer per (device, stream): valid until the next
+    QLoRA call on that stream; work on another stream gets its own buffer instead of racing on this one."""
+    key = (wq.device, torch.cuda.current_stream(wq.device).cuda_stream)
     buf = _dense_scratch.get(key)
     if buf is None or buf.numel() < N * K:
         buf = torch.empty(N * K, dtype=torch.bfloat16, device=wq.device)
         _dense_scratch[key] = buf
     with torch.cuda.device(wq.device):
-        rc = _lib.lib().fastmax_hip_nf4_dequantize(wq.data_ptr(), absmax.data_ptr(), buf.data_ptr(), N * K, _lib.BF16,
-                                                   _stream(wq.device))
-    _lib.check(rc, "fastmax_hip_nf4_dequantize")
+        rc = _lib.lib().fastmax_hip_nf4_dequantize_s(wq.data_ptr(), scales.ref, buf.data_ptr(), N * K, _lib.BF16,
+                                                     _stream(wq.device))
+    _lib.check(rc, "fastmax_hip_nf4_dequantize_s")
     return buf[: N * K].view(N, K)
 
 
@@ -176,45 +295,47 @@ class _QLoRALinearFn(torch.autograd.Function):
     (M >= DENSE_M, bf16): HIP dequant to scratch + library GEMMs.  d(ea), d(eb) are thin library GEMMs."""
 
     @staticmethod
-    def forward(ctx, x2, ea, eb, wq, absmax, bias, N, K, wdense=None):
+    def forward(ctx, x2, ea, eb, wq, scales, bias, N, K, wdense=None):
         M = x2.shape[0]
+        ctx.scales = scales
         dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
         ctx.dense = dt == _lib.BF16 and (M >= DENSE_M or wdense is not None)
         ctx.wdense = wdense
         if ctx.dense:
-            y = x2 @ (wdense if wdense is not None else _dense_weight(wq, absmax, N, K)).t()
+            y = x2 @ (wdense if wdense is not None else _dense_weight(wq, scales, N, K)).t()
             if ea is not None:
                 y.addmm_(ea, eb.t())
             if bias is not None:
                 y += bias.to(y.dtype)
-            ctx.save_for_backward(ea, eb, wq, absmax)
+            ctx.save_for_backward(ea, eb, wq)
             ctx.dims = (M, N, K, dt)
             return y
         y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
         with torch.cuda.device(x2.device):
-            rc = _lib.lib().fastmax_hip_nf4_linear_forward(
-                x2.data_ptr(), x2.stride(0), wq.data_ptr(), absmax.data_ptr(),
+            rc = _lib.lib().fastmax_hip_nf4_linear_forward_s(
+                x2.data_ptr(), x2.stride(0), wq.data_ptr(), scales.ref,
                 None if bias is None else bias.data_ptr(), None if ea is None else ea.data_ptr(),
                 None if eb is None else eb.data_ptr(), y.data_ptr(), N, M, N, K, dt, _stream(x2.device))
-        _lib.check(rc, "fastmax_hip_nf4_linear_forward")
-        ctx.save_for_backward(ea, eb, wq, absmax)
+        _lib.check(rc, "fastmax_hip_nf4_linear_forward_s")
+        ctx.save_for_backward(ea, eb, wq)
         ctx.dims = (M, N, K, dt)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        ea, eb, wq, absmax = ctx.saved_tensors
+        ea, eb, wq = ctx.saved_tensors
+        scales = ctx.scales
         M, N, K, dt = ctx.dims
         dy = dy.contiguous()
         dx = d_ea = d_eb = None
         if ctx.needs_input_grad[0] and ctx.dense:
-            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, absmax, N, K))
+            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, scales, N, K))
         elif ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
             with torch.cuda.device(dy.device):
-                rc = _lib.lib().fastmax_hip_nf4_linear_backward_input(dy.data_ptr(), N, wq.data_ptr(), absmax.data_ptr(),
-                                                                      dx.data_ptr(), K, M, N, K, dt, _stream(dy.device))
-            _lib.check(rc, "fastmax_hip_nf4_linear_backward_input")
+                rc = _lib.lib().fastmax_hip_nf4_linear_backward_input_s(dy.data_ptr(), N, wq.data_ptr(), scales.ref,
+                                                                        dx.data_ptr(), K, M, N, K, dt, _stream(dy.device))
+            _lib.check(rc, "fastmax_hip_nf4_linear_backward_input_s")
         if ea is not None:
             dyb = dy.to(torch.bfloat16)
             if ctx.needs_input_grad[1]:
@@ -319,31 +440,33 @@ class _QLoRAThinFn(torch.autograd.Function):
     one streaming pass each (lit_gpt/lora.py:170-177, 419-433 and their autograd mirror, without dropout)."""
 
     @staticmethod
-    def forward(ctx, x2, A, ebt, wq, absmax, bias, N, K, wdense):
+    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense):
         R, RP = A.shape[0], ebt.shape[0]
+        ctx.scales = scales
         if R == RP:                                   # no padding needed: use A as it is
             abt = A.detach().to(torch.bfloat16).contiguous()
         else:
             abt = torch.zeros((RP, K), dtype=torch.bfloat16, device=x2.device)
             abt[:R] = A.detach()
-        y = x2 @ (wdense if wdense is not None else _dense_weight(wq, absmax, N, K)).t()
+        y = x2 @ (wdense if wdense is not None else _dense_weight(wq, scales, N, K)).t()
         ea, eat = lora_down(x2, abt)
         lora_up_(y, ea, ebt, bias, transposed=True)
-        ctx.save_for_backward(x2, eat, abt, ebt, wq, absmax)
+        ctx.save_for_backward(x2, eat, abt, ebt, wq)
         ctx.wdense = wdense
         ctx.dims = (N, K, R, A.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, eat, abt, ebt, wq, absmax = ctx.saved_tensors
+        x2, eat, abt, ebt, wq = ctx.saved_tensors
+        scales = ctx.scales
         N, K, R, a_dt = ctx.dims
         dy = dy.contiguous()
         dx = dA = d_ebt = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             d_ea, d_eat = lora_down(dy, ebt)
         if ctx.needs_input_grad[0]:
-            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, absmax, N, K))
+            dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, scales, N, K))
             lora_up_(dx, d_ea, abt, transposed=True)
         if ctx.needs_input_grad[1]:
             dA = lora_tn(d_eat, x2, R, a_dt)
@@ -371,7 +494,7 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
+    y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, NF4Scales(base.weight.quant_state), bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -398,7 +521,7 @@ def qlora_linear(x, base: NF4Linear, ea, eb):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, base.weight.quant_state[0], bias, N, K, base._dense_cache)
+    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, NF4Scales(base.weight.quant_state), bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N).to(x.dtype)
 
 
@@ -432,10 +555,11 @@ class LoRALinear(LoRALayer):
             nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
             nn.init.zeros_(self.lora_B)
 
-    def quantize_base(self) -> "LoRALinear":
-        """Swap the dense frozen layer for its NF4 version (what the bnb plugin does at construction)."""
+    def quantize_base(self, double_quant: bool = False) -> "LoRALinear":
+        """Swap the dense frozen layer for its NF4 version (what the bnb plugin does at construction); ``double_quant``:
+        the "bnb.nf4-dq" mode of finetune/lora.py:38 (block scales stored in 8 bits)."""
         if not isinstance(self.linear, NF4Linear):
-            self.linear = NF4Linear.from_linear(self.linear)
+            self.linear = NF4Linear.from_linear(self.linear, double_quant=double_quant)
         return self
 
     def get_lora_AB(self) -> torch.Tensor:
@@ -467,7 +591,7 @@ class LoRALinear(LoRALayer):
             lora_data = self.get_lora_AB()
             if isinstance(self.linear, NF4Linear):
                 w = self.linear.dequantize(torch.float32) + lora_data.float().to(self.linear.weight.device)
-                self.linear.load_dense(w.to(self.linear.weight.quant_state[2]))
+                self.linear.load_dense(w.to(self.linear.weight.quant_state[2]))      # keeps nf4 / nf4-dq as it was
             elif self.linear.weight.data.dtype == lora_data.dtype:
                 self.linear.weight.data += lora_data
             else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 4   /* 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 5   /* 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -235,6 +235,26 @@ int fastmax_hip_nf4_linear_backward_input(const void* dy, int64_t lddy, const ui
 /*      dense dequantisation (merge path: lora.py:142-168 dequantize + add LoRA + requantize)     */
 int fastmax_hip_nf4_dequantize(const uint8_t* wq, const float* absmax, void* out, int64_t n, int dtype,
                                void* stream);
+
+/* ---- double quantisation ("bnb.nf4-dq", finetune/lora.py:38; QLoRA arXiv 2305.14314 section 3): the fp32 block scales are
+ *      themselves stored in 8 bits.  absmax[i] = code2[absmax_q[i]] * absmax2[i / 256] + offset.  The `_s` forms of the three
+ *      entry points above take the scales as this struct (plain NF4: `absmax` set, `absmax_q` NULL).  The 256-entry map and
+ *      the codec live on the host side (lora.py here); bitsandbytes is absent from the reference tree: parity UNPINNED.    */
+typedef struct fastmax_nf4_scales {
+    const float* absmax;      /* plain NF4: fp32, one per 64 weights; ignored when absmax_q != NULL */
+    const uint8_t* absmax_q;  /* nf4-dq: 8-bit code per 64 weights, or NULL                          */
+    const float* absmax2;     /* nf4-dq: fp32 scale per 256 codes                                    */
+    const float* code2;       /* nf4-dq: the 256-entry map (device memory)                           */
+    float offset;             /* nf4-dq: mean of the original absmax vector                          */
+} fastmax_nf4_scales;
+int fastmax_hip_nf4_linear_forward_s(const void* x, int64_t ldx, const uint8_t* wq, const fastmax_nf4_scales* scales,
+                                     const float* bias, const void* ea, const void* eb, void* y, int64_t ldy,
+                                     int M, int N, int K, int dtype, void* stream);
+int fastmax_hip_nf4_linear_backward_input_s(const void* dy, int64_t lddy, const uint8_t* wq,
+                                            const fastmax_nf4_scales* scales, void* dx, int64_t lddx, int M, int N, int K,
+                                            int dtype, void* stream);
+int fastmax_hip_nf4_dequantize_s(const uint8_t* wq, const fastmax_nf4_scales* scales, void* out, int64_t n, int dtype,
+                                 void* stream);
 
 /* ---- QLoRA linear at training sizes: the rank-r products around the library GEMM of the frozen weight
  *      (csrc/lora_thin.hip).  Replaces the tensor ops of lit_gpt/lora.py:170-177 / :419-433 and their autograd mirror

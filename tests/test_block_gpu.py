@@ -242,3 +242,66 @@ def test_block_grouped_route_matches_the_expanded_route(monkeypatch):
             p.grad = None
     for a, b in zip(*res):
         assert float((a.float() - b.float()).abs().max()) <= 3e-2 * float(b.float().abs().max())
+
+
+def _dense_block_fp32(blk, x, cos, sin, A, Bm, p):
+    """float32 torch evaluation of the sub-layer with DENSE attention f(QK^T)V (known-answer form, fastmax.py:336-381 + 103)
+    on the dequantised weights; A, Bm are float32 leaf copies of attn.lora_A / attn.lora_B so autograd gives their gradients."""
+    from fastmax_experiments_amd.attention_block import apply_rope
+    B, T, _ = x.shape
+    w = blk.attn.linear.dequantize(torch.float32)
+    qpk = blk.n_head // blk.n_query_groups
+    rows = torch.zeros(blk.attn.linear.out_features, A.shape[0], device=x.device)
+    ind = blk.attn._ind.to(x.device)
+    rows = rows.index_put((ind[:, None].expand(-1, blk.attn.r), blk.attn._cols.to(x.device)), Bm)
+    qkv = x @ w.T + (x @ A.T) @ rows.T * blk.attn.scaling
+    qkv5 = qkv.view(B, T, blk.n_query_groups, qpk + 2, blk.head_size)
+    q = qkv5[:, :, :, :qpk].permute(0, 2, 3, 1, 4).reshape(B, blk.n_head, T, blk.head_size)
+    k, v = (qkv5[:, :, :, qpk + i].permute(0, 2, 1, 3).repeat_interleave(qpk, dim=1) for i in (0, 1))
+    n = blk.rope_n_elem
+    q = torch.cat((apply_rope(q[..., :n], cos, sin), q[..., n:]), -1)
+    k = torch.cat((apply_rope(k[..., :n], cos, sin), k[..., n:]), -1)
+    s = (q @ k.transpose(-1, -2)) / (8.0 * blk.head_size ** 0.5)
+    P = torch.tril(1 + s + (0.5 * s * s if p == 2 else 0))
+    y = (P @ v) / P.sum(-1, keepdim=True)
+    y = y.reshape(B, T, blk.head_size * blk.n_head)                     # quirk Q3: no transpose
+    return y @ blk.proj.linear.dequantize(torch.float32).T
+
+
+def test_qlora_block_gradients_against_dense_fp32():
+    """gradients of the whole QLoRA attention sub-layer (NF4 linears with LoRA on q, v -> RoPE / GQA split -> fastmax p=2 ->
+    proj) w.r.t. the input and both LoRA matrices against float32 autograd through a dense evaluation of the same block"""
+    from fastmax_experiments_amd.attention_block import CausalSelfAttention, build_rope_cache
+    torch.manual_seed(3)
+    blk = CausalSelfAttention(256, 8, n_query_groups=2, attn_alg="fastmax", r=8, alpha=16)
+    torch.nn.init.normal_(blk.attn.lora_B, std=0.05)
+    blk.quantize_base().cuda()
+    T = 320
+    cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    x0 = torch.randn(2, T, 256, device="cuda")
+    gy = torch.randn(2, T, 256, device="cuda")
+    x = x0.to(torch.bfloat16).requires_grad_(True)
+    y = blk(x, cos.to(torch.bfloat16), sin.to(torch.bfloat16))
+    y.backward(gy.to(torch.bfloat16))
+    xr = x0.to(torch.bfloat16).float().requires_grad_(True)
+    A = blk.attn.lora_A.detach().float().clone().requires_grad_(True)
+    Bm = blk.attn.lora_B.detach().float().clone().requires_grad_(True)
+    yr = _dense_block_fp32(blk, xr, cos, sin, A, Bm, 2)
+    yr.backward(gy.to(torch.bfloat16).float())
+    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy()) < 3e-2
+    for got, want, name in ((x.grad, xr.grad, "x"), (blk.attn.lora_A.grad, A.grad, "lora_A"), (blk.attn.lora_B.grad, Bm.grad, "lora_B")):
+        assert rel_err(got.float().cpu().numpy(), want.cpu().numpy()) < 4e-2, name
+
+
+def test_bench_dp_step_on_device():
+    """`bench.py --workload dp_step` with the real QLoRA stack on the card: one rank, and two ranks over gloo sharing the one
+    GPU (rehearsal of the N > 1 control flow; the RCCL path needs one GPU per rank and runs in the driver's scaling bench)"""
+    from test_dp_gloo import _run_bench
+    common = ["--workload", "dp_step", "--config", "pythia-14m", "--layers", "2", "--seq", "256", "--steps", "2", "--warmup", "1",
+              "--precondition-ms", "0"]
+    one = _run_bench(common, 1)
+    assert one["n_gpus"] == 1 and one["allreduce"]["backend"].startswith("none") and one["value"] > 0
+    assert one["trainable_params"] == 2 * (16 * 128 + 2 * 128 * 8)          # r = 8 on q, v of two layers (A: 16 x 128, B: 256 x 8)
+    two = _run_bench(common, 2, env={"FASTMAX_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["allreduce"]["backend"] == "gloo" and two["config"]["global_batch"] == 8
+    assert two["last_loss"] == two["last_loss"] and two["allreduce"]["bucket_bytes"] == 4 * two["trainable_params"]

@@ -114,3 +114,33 @@ def test_accumulation_iters_follow_reference_args():
     assert t.gradient_accumulation_iters(1) == 16 and t.gradient_accumulation_iters(8) == 2
     with pytest.raises(AssertionError):
         dp.TrainArgs(global_batch_size=8, micro_batch_size=4).gradient_accumulation_iters(8)
+
+
+def _run_bench(args, nproc, env=None):
+    import json
+    import subprocess
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout                      # rank 0 prints exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_dp_step_mode_two_ranks_over_gloo():
+    """`bench.py --workload dp_step` launched the way the driver launches N > 1 (torch.distributed.run, one process per
+    rank): the multi-rank control flow -- sharded batch, accumulation, one all-reduce per optimizer step, MAX over ranks,
+    one JSON line -- rehearsed on CPU ranks with the stand-in model (the attention operator has no CPU path)."""
+    one = _run_bench(["--workload", "dp_step", "--toy", "--steps", "3", "--warmup", "1", "--seq", "16"], 1)
+    two = _run_bench(["--workload", "dp_step", "--toy", "--steps", "3", "--warmup", "1", "--seq", "16"], 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["workload"] == "dp_step"
+    assert two["config"]["global_batch"] == 2 * one["config"]["global_batch"]            # weak scaling: per-rank work fixed
+    assert two["allreduce"]["backend"] == "gloo" and two["allreduce"]["per_step"] == 1
+    assert two["allreduce"]["bucket_bytes"] == one["allreduce"]["bucket_bytes"] == 4 * two["trainable_params"]
+    assert two["value"] > 0 and two["ms_per_step"] > 0 and two["last_loss"] == two["last_loss"]

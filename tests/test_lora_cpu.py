@@ -162,3 +162,51 @@ def test_nf4linear_state_dict_round_trip():
     q2 = lora.NF4Linear(128, 64)
     q2.load_state_dict(sd)
     assert torch.equal(q2.dequantize(), q.dequantize())
+
+
+def test_double_quantised_block_scales_codec():
+    """"bnb.nf4-dq" (finetune/lora.py:38; QLoRA section 3): absmax - mean stored as 8-bit codes of the 256-level dynamic map,
+    block 256, one fp32 scale per block.  bitsandbytes is absent: self-consistency only (parity unpinned)."""
+    code2 = lora.dynamic_map_8bit()
+    assert code2.numel() == 256 and torch.unique(code2).numel() == 256 and torch.equal(code2, code2.sort().values)
+    assert float(code2[-1]) == 1.0 and 0.0 in code2.tolist() and float(code2[0]) < -0.99        # signed map, not symmetric
+    g = torch.Generator().manual_seed(3)
+    absmax = torch.rand(700, generator=g) * 0.2 + 0.01                    # ragged: 700 = 2 blocks of 256 + 188
+    codes, absmax2, offset, c2 = lora.absmax_double_quantize(absmax)
+    assert codes.dtype == torch.uint8 and codes.numel() == 700 and absmax2.numel() == 3 and offset.ndim == 0
+    assert abs(float(offset) - float(absmax.mean())) < 1e-7
+    back = lora.absmax_double_dequantize(codes, absmax2, offset, c2)
+    # nearest-code property: no other map entry reproduces a scale better
+    scaled = (absmax - offset) / absmax2[torch.arange(700) // 256]
+    best = (scaled[:, None] - c2[None, :]).abs().min(dim=1).values
+    assert torch.allclose((scaled - c2[codes.long()]).abs(), best, atol=1e-7)
+    assert float(((back - absmax).abs() / absmax2[torch.arange(700) // 256]).max()) < 0.04      # coarsest map spacing, relative to the block
+
+
+def test_nf4_double_quant_layer_state_and_copies():
+    import copy
+    lin = torch.nn.Linear(128, 64)
+    q = lora.NF4Linear.from_linear(lin, double_quant=True)
+    plain = lora.NF4Linear.from_linear(lin)
+    qs = q.weight.quant_state
+    assert q.double_quant and not plain.double_quant
+    assert qs[0].dtype == torch.uint8 and qs[0].numel() == 128 * 64 // 64 and tuple(qs[1]) == (64, 128) and qs[5] == "nf4"
+    assert torch.equal(q.weight.data, plain.weight.data)                  # the 4-bit codes do not change, only the scales
+    w_dq, w = q.dequantize(), plain.dequantize()
+    assert 0 < float((w_dq - w).abs().max()) < 0.02 * float(w.abs().max())
+    # deepcopy (nn.Parameter.__deepcopy__ calls type(self)(data, requires_grad)) keeps an independent quant_state
+    q2 = copy.deepcopy(q)
+    assert q2.weight.quant_state is not qs and q2.weight.quant_state[0] is not qs[0] and torch.equal(q2.dequantize(), w_dq)
+    p2 = copy.deepcopy(plain.weight)
+    assert isinstance(p2, lora.Params4bit) and torch.equal(p2.quant_state[0], plain.weight.quant_state[0])
+    # state_dict round trip carries the double-quantised scales
+    q3 = lora.NF4Linear(128, 64)
+    q3.load_state_dict(q.state_dict())
+    assert q3.double_quant and torch.equal(q3.dequantize(), w_dq)
+    # merge keeps the mode (lora.py:142-168: dequantise + add + requantise)
+    lay = lora.LoRALinear(128, 64, r=4, lora_alpha=8)
+    torch.nn.init.normal_(lay.lora_B, std=0.05)
+    lay.quantize_base(double_quant=True)
+    before = lay.linear.dequantize()
+    lay.merge()
+    assert lay.linear.double_quant and float((lay.linear.dequantize() - before - lay.get_lora_AB()).abs().max()) < 0.2 * float(before.abs().max())

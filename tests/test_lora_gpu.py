@@ -298,3 +298,41 @@ def test_lora_up_transposed_operand():
     a = lora.lora_up_(y0.clone(), e, bn)
     b = lora.lora_up_(y0.clone(), e, bn.t().contiguous(), transposed=True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (16, 2048, 2560), (2500, 512, 1088)])   # tile kernel, generation kernel, decode-once route
+def test_nf4_double_quant_kernels_match_the_codec(M, K, N):
+    """"bnb.nf4-dq": the kernels decode the 8-bit block scales themselves (one map lookup + fma per 64 weights).  HIP dequantise
+    == host codec bit for bit, and the linear (forward and input gradient) == dense math on the dequantised weight."""
+    from fastmax_experiments_amd import lora
+    g = torch.Generator().manual_seed(K + N)
+    lin = torch.nn.Linear(K, N)
+    torch.nn.init.normal_(lin.weight, generator=g)
+    q = lora.NF4Linear.from_linear(lin, double_quant=True)
+    host = q.dequantize(torch.float32)
+    q = q.cuda()
+    assert q.double_quant and q.weight.quant_state[0].dtype == torch.uint8 and q.weight.quant_state[4][1][0].is_cuda
+    wd = q.dequantize(torch.float32)
+    assert torch.equal(wd.cpu(), host)
+    assert torch.equal(q.dequantize(torch.bfloat16).cpu(), host.to(torch.bfloat16))
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+    y = q(x)
+    ref = x.detach().float() @ wd.to(torch.bfloat16).float().T + q.bias.float()
+    assert _rel(y, ref) < 1.5e-2
+    gy = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    y.backward(gy)
+    assert _rel(x.grad, gy.float() @ wd.to(torch.bfloat16).float()) < 1.5e-2
+
+
+def test_qlora_layer_with_double_quantised_base():
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(5)
+    layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=(True, False, True))
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base(double_quant=True).cuda()
+    for rows in (75, 1200):                                      # fused kernel / decode-once route (2 x 1200 rows >= DENSE_M)
+        x = torch.randn(2, rows, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        y = layer(x)
+        assert _rel(y, _dense_reference(layer, x.detach())) < 2e-2
+        y.backward(torch.randn_like(y))
+        assert torch.isfinite(layer.lora_A.grad).all() and layer.linear.weight.grad is None

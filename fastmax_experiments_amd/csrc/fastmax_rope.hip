@@ -17,6 +17,8 @@ struct RopeParams {
     void *q, *k, *v;          // forward outputs / backward inputs (gradients)
     const float *cos, *sin;
     int B, T, G, qpk, hs, rope_n, expand_kv;
+    int tables16;             // the caller's rope cache was in the tensors' own 16-bit dtype ("bf16-true" precision): the two
+                              // products are rounded to that dtype before the sum, as the tensor ops of model.py:708 then do
 };
 
 template <typename T, int E> __device__ __forceinline__ void ld_piece(const T* p, float (&x)[E]) {
@@ -116,8 +118,13 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(RopeParams prm) {
                 // out[d] = x[d] cos[d] - x[d+half] sin[d];  out[d+half] = x[d+half] cos[d+half] + x[d] sin[d+half]
                 // with the reference's roundings (model.py:708: two float32 products, one float32 sum, one rounding to the
                 // tensor dtype) -- no fused multiply-add, so 16-bit results are bit-identical to the tensor ops
-                lo[e] = mul_add_unfused(a, c0, -bb, s0);
-                hi[e] = mul_add_unfused(bb, c1, a, s1);
+                if (sizeof(T) == 2 && prm.tables16) {
+                    lo[e] = to_float(from_float<T>(a * c0)) + to_float(from_float<T>(-bb * s0));
+                    hi[e] = to_float(from_float<T>(bb * c1)) + to_float(from_float<T>(a * s1));
+                } else {
+                    lo[e] = mul_add_unfused(a, c0, -bb, s0);
+                    hi[e] = mul_add_unfused(bb, c1, a, s1);
+                }
             } else {
                 // transpose of the map above
                 lo[e] = a * c0 + bb * s1;
@@ -180,7 +187,7 @@ int fastmax_hip_rope_qkv_split(const void* qkv, const float* cos, const float* s
                                int q_per_kv, int head_size, int rope_n_elem, int expand_kv, int dtype, void* stream) {
     const int rc = rope_check(qkv, q, k, v, cos, sin, B, T, G, q_per_kv, head_size, rope_n_elem, dtype);
     if (rc) return rc;
-    RopeParams prm{qkv, q, k, v, cos, sin, B, T, G, q_per_kv, head_size, rope_n_elem, expand_kv};
+    RopeParams prm{qkv, q, k, v, cos, sin, B, T, G, q_per_kv, head_size, rope_n_elem, expand_kv & 3, (expand_kv >> 4) & 1};
     return launch_rope_qkv(prm, dtype, false, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -190,7 +197,7 @@ int fastmax_hip_rope_qkv_split_backward(const void* grad_q, const void* grad_k, 
     const int rc = rope_check(grad_qkv, grad_q, grad_k, grad_v, cos, sin, B, T, G, q_per_kv, head_size, rope_n_elem, dtype);
     if (rc) return rc;
     RopeParams prm{grad_qkv, const_cast<void*>(grad_q), const_cast<void*>(grad_k), const_cast<void*>(grad_v), cos, sin, B, T, G,
-                   q_per_kv, head_size, rope_n_elem, expand_kv};
+                   q_per_kv, head_size, rope_n_elem, expand_kv & 3, 0};
     return launch_rope_qkv(prm, dtype, true, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -43,7 +43,8 @@ struct Nf4Scale {
     const float* code2;       // dq: 256-entry map
     float offset;
     __device__ __forceinline__ float operator[](int64_t blk) const {
-        return q ? fmaf(code2[q[blk]], absmax2[blk >> 8], offset) : absmax[blk];
+        // product and sum rounded separately (no fused multiply-add): bit-identical to the host codec (lora.py)
+        return q ? __fadd_rn(__fmul_rn(code2[q[blk]], absmax2[blk >> 8]), offset) : absmax[blk];
     }
 };
 

@@ -69,6 +69,20 @@ class _CrossEntropyRows(torch.autograd.Function):
         return out, None, None
 
 
+def scored_rows(targets: torch.Tensor, vocab: int, ignore_index: int) -> torch.Tensor:
+    """the rows the kernel scores: a label that is not `ignore_index` and lies inside [0, vocab).  torch's cross_entropy (what
+    lit_gpt/utils.py:228-272 calls) raises a device assert for any other label; the kernel gives such a row loss 0 and a zero
+    gradient, so the mean's denominator counts exactly these rows -- and `check_targets` raises like the reference."""
+    return (targets != ignore_index) & (targets >= 0) & (targets < vocab)
+
+
+def check_targets(targets: torch.Tensor, vocab: int, ignore_index: int = -1) -> None:
+    """raise for labels outside [0, vocab) other than `ignore_index` (one host sync: for tests and debugging, not the step)"""
+    bad = (targets != ignore_index) & ((targets < 0) | (targets >= vocab))
+    if bool(bad.any()):
+        raise ValueError(f"cross entropy target {int(targets[bad][0])} is outside [0, {vocab}) and is not ignore_index={ignore_index}")
+
+
 def cross_entropy_rows(logits, targets, ignore_index=-100):
     logits2d, targets1d = _prep(logits, targets)
     return _CrossEntropyRows.apply(logits2d, targets1d, ignore_index)
@@ -83,9 +97,11 @@ def chunked_cross_entropy(logits: Union[torch.Tensor, List[torch.Tensor]], targe
         parts = [cross_entropy_rows(chunk, t, ignore_index)
                  for chunk, t in zip(logits, targets.split(logits[0].size(1), dim=1))]
         rows = torch.cat(parts)
+        vocab = logits[0].size(-1)
     else:
         rows = cross_entropy_rows(logits, targets, ignore_index)
-    non_masked_elems = (targets != ignore_index).sum()
+        vocab = logits.size(-1)
+    non_masked_elems = scored_rows(targets, vocab, ignore_index).sum()
     return rows.sum() / non_masked_elems.clamp(min=1)
 
 
@@ -102,7 +118,7 @@ class _LMHeadLoss(torch.autograd.Function):
             loss, l = _rows_forward(logits, targets1d[r0:r0 + chunk_rows], ignore_index)
             lse[r0:r0 + chunk_rows] = l
             total += loss.sum()
-        n = (targets1d != ignore_index).sum().clamp(min=1)
+        n = scored_rows(targets1d, weight.shape[0], ignore_index).sum().clamp(min=1)
         ctx.save_for_backward(x2d, weight, targets1d, lse, n)
         ctx.ignore_index, ctx.chunk_rows = ignore_index, chunk_rows
         return (total / n).to(x2d.dtype)

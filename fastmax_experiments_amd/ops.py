@@ -233,6 +233,9 @@ class RopeQKVSplit(torch.autograd.Function):
         B, T, G, total, hs = qkv.shape
         qpk = total - 2
         qkv = qkv.contiguous()
+        # a rope cache kept in the tensors' own 16-bit dtype ("bf16-true"): model.py:708 then rounds each product to that
+        # dtype before the sum -- the kernel reproduces those roundings (tables travel as exact float32 copies)
+        tables16 = 16 if (cos.dtype == qkv.dtype and qkv.dtype in (torch.bfloat16, torch.float16)) else 0
         cos = cos[:T, :rope_n_elem].float().contiguous()
         sin = sin[:T, :rope_n_elem].float().contiguous()
         q = torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device)
@@ -240,7 +243,7 @@ class RopeQKVSplit(torch.autograd.Function):
         v = torch.empty((B, G * qpk if expand in (1, 2) else G, T, hs), dtype=qkv.dtype, device=qkv.device)
         with torch.cuda.device(qkv.device):
             rc = L.fastmax_hip_rope_qkv_split(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
-                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, int(expand), _DT[qkv.dtype],
+                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, int(expand) | tables16, _DT[qkv.dtype],
                                               _stream(qkv.device))
         _lib.check(rc, "fastmax_hip_rope_qkv_split")
         ctx.save_for_backward(cos, sin)

@@ -179,8 +179,12 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
  *      RoPE (apply_rope, model.py:702-708) on the first rope_n_elem elements of q and k with cos, sin: (T, rope_n_elem) float32.
  *      Replaces view/permute/split/expand/reshape copies + five elementwise launches + two cats per tensor.
  *      rope_n_elem / 2 and head_size - rope_n_elem must be multiples of 16 bytes of elements (else FASTMAX_E_BAD_SHAPE).
+ *      expand_kv: bits 0-1 = 0 (k, v stay at G heads) / 1 (both repeated per query head) / 2 (only v);  bit 4
+ *      (FASTMAX_ROPE_TABLES_16BIT): the caller's rope cache was in the tensors' own 16-bit dtype ("bf16-true"): the two products
+ *      are rounded to that dtype before they are summed, which is what the tensor ops of model.py:708 then compute.
  *      _backward: gradients of q, k, v in the same layouts -> gradient of qkv (sum over the query heads of a group for k, v,
  *      inverse rotation, re-interleave).                                                                               */
+#define FASTMAX_ROPE_TABLES_16BIT 16
 int fastmax_hip_rope_qkv_split(const void* qkv, const float* cos, const float* sin, void* q, void* k, void* v,
                                int B, int T, int G, int q_per_kv, int head_size, int rope_n_elem, int expand_kv,
                                int dtype, void* stream);

@@ -156,6 +156,31 @@ def test_fused_neighbours_kernel_matches_the_tensor_ops(B, T, G, qpk, hs, rot, d
     assert rel_err(a.grad.float().cpu().numpy(), b.grad.float().cpu().numpy()) < (1e-6 if dt == torch.float32 else 6e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fused_neighbours_with_a_16bit_rope_cache(dt):
+    """"bf16-true" precision keeps the rope cache in the tensors' dtype: apply_rope (model.py:702-708) then rounds x cos and
+    rot(x) sin to 16 bits before adding them.  The kernel reproduces those roundings bit for bit (checked against the
+    tensor-op sequence run with 16-bit tables; the reference's own module cannot be imported here: parity of this row is
+    pinned only through this restatement)."""
+    from fastmax_experiments_amd import ops
+    from fastmax_experiments_amd.attention_block import apply_rope, build_rope_cache
+    B, T, G, qpk, hs = 2, 131, 2, 4, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, T, G, qpk + 2, hs, generator=g).to(dt).cuda()
+    cos, sin = (t.to(dt) for t in build_rope_cache(T, hs, device="cuda"))
+    y = qkv.permute(0, 2, 3, 1, 4)
+    q, k, v = y.split((qpk, 1, 1), dim=2)
+    q = q.reshape(B, -1, T, hs)
+    k = k.expand(B, G, qpk, T, hs).reshape(B, -1, T, hs)
+    want_q, want_k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    assert want_q.dtype == dt
+    got_q, got_k, _ = ops.RopeQKVSplit.apply(qkv, cos, sin, hs)
+    assert torch.equal(got_q, want_q) and torch.equal(got_k, want_k)
+    # and float32 tables still give the float32-product result (differs from the 16-bit-table one in the last bit somewhere)
+    q32, _, _ = ops.RopeQKVSplit.apply(qkv, cos.float(), sin.float(), hs)
+    assert torch.equal(q32, apply_rope(q, cos.float(), sin.float()))
+
+
 def test_block_with_and_without_fused_neighbours():
     from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache
     torch.manual_seed(0)

@@ -80,3 +80,31 @@ def test_cpu_tensors_are_refused():
     from fastmax_experiments_amd.loss import chunked_cross_entropy
     with pytest.raises(RuntimeError):
         chunked_cross_entropy(torch.randn(1, 4, 10), torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_labels_outside_the_vocabulary():
+    """-100 labels under ignore_index=-1 (a common mix-up): torch raises a device assert; here the kernel scores such rows 0
+    with a zero gradient AND the mean's denominator leaves them out (it used to count them: a silently smaller loss);
+    `check_targets` raises like the reference."""
+    from fastmax_experiments_amd.loss import check_targets, chunked_cross_entropy, lm_head_cross_entropy
+    g = torch.Generator().manual_seed(2)
+    V = 96
+    logits = torch.randn(2, 40, V, generator=g).cuda().requires_grad_(True)
+    targets = torch.randint(0, V, (2, 40), generator=g).cuda()
+    targets[0, :5] = -100
+    targets[1, 3] = V + 7
+    targets[1, 4] = -1                                               # the real ignore_index
+    loss = chunked_cross_entropy(logits, targets, chunk_size=0, ignore_index=-1)
+    keep = (targets >= 0) & (targets < V)
+    ref = F.cross_entropy(logits.detach()[keep], targets[keep], reduction="mean")
+    assert abs(float(loss) - float(ref)) < 1e-5
+    loss.backward()
+    assert float(logits.grad[0, :5].abs().sum()) == 0.0 and float(logits.grad[1, 3].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        check_targets(targets, V, ignore_index=-1)
+    check_targets(targets.clamp(0, V - 1), V, ignore_index=-1)
+    x = torch.randn(80, 32, generator=g).cuda()
+    w = torch.randn(V, 32, generator=g).cuda()
+    l2 = lm_head_cross_entropy(x, w, targets.reshape(-1), ignore_index=-1, chunk_rows=32)
+    ref2 = F.cross_entropy((x @ w.T)[keep.reshape(-1)], targets.reshape(-1)[keep.reshape(-1)], reduction="mean")
+    assert abs(float(l2) - float(ref2)) < 2e-3

@@ -49,6 +49,7 @@ class CausalSelfAttention(nn.Module):
             raise ValueError(f"Attention algorithm {attn_alg} not supported")          # model.py:450-451
         self.attn_alg = attn_alg
         self.fused_neighbours = True          # False: tensor-op slicing instead of the one-pass HIP kernel (A/B, parity tests)
+        self.group_views = True               # grouped-query heads: K, V never copied per query head (False: the reference's expand)
         shape = (n_head + 2 * self.n_query_groups) * self.head_size
         self.attn = LoRAQKVLinear(n_embd, shape, n_head=n_head, n_query_groups=self.n_query_groups, r=r, lora_alpha=alpha,
                                   lora_dropout=dropout, enable_lora=(to_query, to_key, to_value), bias=bias)
@@ -72,18 +73,20 @@ class CausalSelfAttention(nn.Module):
         grouped = (fused and self.attn_alg == "linearmax" and q_per_kv > 1 and torch.is_grad_enabled() and
                    (x.requires_grad or any(p.requires_grad for p in self.attn.parameters())) and
                    grouped_route_supported(x.device, qkv.dtype, self.head_size, B * self.n_head))
+        views = fused and q_per_kv > 1 and self.group_views
         if grouped:
             # training, grouped-query heads: K stays at its n_query_groups heads through RoPE and the linearmax prologue
-            # (statistics and gradient once per key head); the prologue's store writes the per-query-head copies
+            # (statistics and gradient once per key head).  group_views: neither K nor V is ever copied per query head --
+            # (batch, group) is the kernels' batch axis and K, V are stride-0 views; else the prologue's store writes the copies
             q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
-                                             self.rope_n_elem, 2)
+                                             self.rope_n_elem, 4 if views else 2)
             y = fastmax_hack_grouped(q, k, v, q_per_kv, p=1)
             y = y.reshape(B, T, self.head_size * self.n_head)      # model.py:453-455 (no transpose: quirk Q3)
             return self.proj(y)
         elif fused:
-            # de-interleave + RoPE + GQA expand in one HIP pass, same values as the tensor ops below
+            # de-interleave + RoPE (+ GQA expand, or group views: see ops.RopeQKVSplit) in one HIP pass
             q, k, v = ops.RopeQKVSplit.apply(qkv.view(B, T, self.n_query_groups, total_qkv, self.head_size), cos, sin,
-                                             self.rope_n_elem)
+                                             self.rope_n_elem, 3 if views else 1)
         else:
             # shapes the one-pass kernel does not take (decode with input_pos, rotary widths that are not whole 16-byte
             # pieces): plain slicing of the (B, T, group, slot, hs) view -- slots 0..q_per_kv-1 are the group's query heads,

@@ -21,13 +21,20 @@ class _NormalizeQK(torch.autograd.Function):
     float32 kernel and the tensor-op backward below."""
 
     @staticmethod
-    def forward(ctx, x, rep=1):
-        r = ops.normalize_cast(x, rep)
+    def forward(ctx, x, rep=1, view=False):
+        """rep > 1 (x holds the G key heads of grouped-query attention): the result serves the G * rep query heads -- as
+        copies (B, G*rep, N, D) written by the prologue's store, or with ``view`` as a stride-0 view (B*G, rep, N, D) of
+        the G normalised heads (nothing is copied; the attention kernels' strides do the group indexing).  Either way the
+        gradient arrives per query head and the backward pass sums a group while it reads."""
+        r = ops.normalize_cast(x, 1 if view else rep)
         ctx.rep = rep
         if r is not None:
             y, inv = r
             ctx.save_for_backward(x, inv)
             ctx.fused = True
+            if view and rep > 1:
+                B, G, N, D = x.shape
+                return y.view(B * G, 1, N, D).expand(B * G, rep, N, D)
             return y
         if rep != 1:
             raise NotImplementedError("grouped normalisation needs a head size that is a whole number of 16-byte pieces")
@@ -41,7 +48,7 @@ class _NormalizeQK(torch.autograd.Function):
     def backward(ctx, gy):
         if ctx.fused:
             x, inv = ctx.saved_tensors
-            return ops.normalize_backward(x, gy, inv, ctx.rep), None
+            return ops.normalize_backward(x, gy, inv, ctx.rep), None, None
         y, inv = ctx.saved_tensors                     # y = xc / M, inv = 1 / M
         gy = gy.float()
         gxc = gy * inv[..., None, None]
@@ -51,7 +58,7 @@ class _NormalizeQK(torch.autograd.Function):
         ystar = torch.gather(y, 2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]))
         gxc.scatter_add_(2, nstar[..., None, None].expand(-1, -1, 1, y.shape[-1]), dLdM[..., None, None] * ystar)
         gx = gxc - gxc.mean(-1, keepdim=True)
-        return gx.to(ctx.in_dtype), None
+        return gx.to(ctx.in_dtype), None, None
 
 
 def fastmax_hack(q, k, v, p=1, mask=True):
@@ -86,12 +93,16 @@ def fastmax_hack(q, k, v, p=1, mask=True):
 
 
 def fastmax_hack_grouped(q, k_groups, v, rep, p=1):
-    """Masked linearmax for grouped-query attention on the training route: q (B,H,N,D), v (B,H,N,D) already repeated,
-    k_groups (B,G,N,D) with H = G * rep.  Same values as fastmax_hack(q, expand(k_groups), v, p, mask=True): the max-norm
-    statistics of identical head copies are identical, so the prologue runs once per key head and writes the H copies the
-    attention reads (the reference expands first, model.py:404-411, and normalises every copy, fastmax_hack.py:38-43)."""
+    """Masked linearmax for grouped-query attention on the training route: k_groups (B,G,N,D) with H = G * rep query heads.
+    Same values as fastmax_hack(q, expand(k_groups), v, p, mask=True): the max-norm statistics of identical head copies
+    are identical, so the prologue runs once per key head (the reference expands first, model.py:404-411, and normalises
+    every copy, fastmax_hack.py:38-43).  Two layouts:
+      q, v (B,H,N,D) with v already repeated         -> the prologue's store writes the H normalised copies of K
+      q, v (B*G, rep, N, D) (v a stride-0 group view) -> K is normalised at its G heads and handed on as a stride-0 view too:
+                                                        no per-query-head copy of K or V exists anywhere"""
+    views = q.shape[0] == k_groups.shape[0] * k_groups.shape[1] and q.shape[1] == rep and rep > 1
     qn = _NormalizeQK.apply(q, 1)
-    kn = _NormalizeQK.apply(k_groups, rep)
+    kn = _NormalizeQK.apply(k_groups, rep, views)
     o = fastattention_einops.apply(qn, kn, v, True, 1, True, p, 0.0, False)
     return o.to(q.dtype)
 

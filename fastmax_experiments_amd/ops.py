@@ -227,8 +227,15 @@ class RopeQKVSplit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, cos, sin, rope_n_elem, expand=1):
-        """expand: 1 = k and v repeated for the query heads of their group (B,H,T,hs); 2 = only v, k stays (B,G,T,hs);
-        0 = neither"""
+        """expand: what the key / value heads look like to the attention that follows (H = G * q_per_kv query heads):
+          0  k, v stay at their G heads (B,G,T,hs)
+          1  k, v COPIED for the query heads of their group (B,H,T,hs) -- the reference's expand + reshape, model.py:404-420
+          2  k stays (B,G,T,hs), v copied
+          3  nothing is copied: q comes back as (B*G, q_per_kv, T, hs) and k, v as views of the G-head tensors with head
+             stride 0, shaped the same -- (batch, group) becomes the batch axis and the kernels' own strides do the
+             group indexing, so every query head of a group reads the same K, V rows; the gradients then arrive per
+             query head and the backward pass sums them over the group while it reads them
+          4  k stays (B,G,T,hs) (for the linearmax prologue, which normalises per key head), q and v as in 3"""
         L = _lib.lib()
         B, T, G, total, hs = qkv.shape
         qpk = total - 2
@@ -238,16 +245,22 @@ class RopeQKVSplit(torch.autograd.Function):
         tables16 = 16 if (cos.dtype == qkv.dtype and qkv.dtype in (torch.bfloat16, torch.float16)) else 0
         cos = cos[:T, :rope_n_elem].float().contiguous()
         sin = sin[:T, :rope_n_elem].float().contiguous()
+        k_copies, v_copies = expand == 1, expand in (1, 2)
+        kern_expand = 1 if (k_copies and v_copies) else (2 if v_copies else 0)          # what the forward pass materialises
         q = torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device)
-        k = torch.empty((B, G * qpk if expand == 1 else G, T, hs), dtype=qkv.dtype, device=qkv.device)
-        v = torch.empty((B, G * qpk if expand in (1, 2) else G, T, hs), dtype=qkv.dtype, device=qkv.device)
+        k = torch.empty((B, G * qpk if k_copies else G, T, hs), dtype=qkv.dtype, device=qkv.device)
+        v = torch.empty((B, G * qpk if v_copies else G, T, hs), dtype=qkv.dtype, device=qkv.device)
         with torch.cuda.device(qkv.device):
             rc = L.fastmax_hip_rope_qkv_split(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(), k.data_ptr(),
-                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, int(expand) | tables16, _DT[qkv.dtype],
+                                              v.data_ptr(), B, T, G, qpk, hs, rope_n_elem, kern_expand | tables16, _DT[qkv.dtype],
                                               _stream(qkv.device))
         _lib.check(rc, "fastmax_hip_rope_qkv_split")
         ctx.save_for_backward(cos, sin)
         ctx.dims = (B, T, G, qpk, hs, rope_n_elem, int(expand))
+        if expand in (3, 4):
+            def group_view(t):
+                return t.view(B * G, 1, T, hs).expand(B * G, qpk, T, hs)
+            return q.view(B * G, qpk, T, hs), (group_view(k) if expand == 3 else k), group_view(v)
         return q, k, v
 
     @staticmethod
@@ -255,11 +268,14 @@ class RopeQKVSplit(torch.autograd.Function):
         L = _lib.lib()
         cos, sin = ctx.saved_tensors
         B, T, G, qpk, hs, rope_n_elem, expand = ctx.dims
+        # modes 3 / 4: gradients of the stride-0 views arrive dense, one per query head, laid out (B*G, qpk, T, hs) =
+        # (B, H, T, hs): exactly what the kernel's group-summing read expects for copied heads
+        kern_expand = {0: 0, 1: 1, 2: 2, 3: 1, 4: 2}[expand]
         gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
         gqkv = torch.empty((B, T, G, qpk + 2, hs), dtype=gq.dtype, device=gq.device)
         with torch.cuda.device(gq.device):
             rc = L.fastmax_hip_rope_qkv_split_backward(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                       gqkv.data_ptr(), B, T, G, qpk, hs, rope_n_elem, expand, _DT[gq.dtype],
+                                                       gqkv.data_ptr(), B, T, G, qpk, hs, rope_n_elem, kern_expand, _DT[gq.dtype],
                                                        _stream(gq.device))
         _lib.check(rc, "fastmax_hip_rope_qkv_split_backward")
         return gqkv, None, None, None, None

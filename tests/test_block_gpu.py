@@ -330,3 +330,52 @@ def test_bench_dp_step_on_device():
     two = _run_bench(common, 2, env={"FASTMAX_BENCH_BACKEND": "gloo"})
     assert two["n_gpus"] == 2 and two["allreduce"]["backend"] == "gloo" and two["config"]["global_batch"] == 8
     assert two["last_loss"] == two["last_loss"] and two["allreduce"]["bucket_bytes"] == 4 * two["trainable_params"]
+
+
+@pytest.mark.parametrize("alg", ["fastmax", "linearmax"])
+@pytest.mark.parametrize("train", [True, False])
+def test_group_views_match_the_expanded_copies_bit_for_bit(alg, train):
+    """grouped-query heads with K, V as stride-0 views over (batch x group) -- no per-query-head copy of K or V is ever
+    written -- against the same block with the reference's expand (model.py:404-420) materialised: the attention kernels
+    see the same values through different strides, so outputs and every gradient are the same bits."""
+    from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache
+    torch.manual_seed(31)
+    cfg = CONFIG_SHAPES["tiny-llama-1.1b"]
+    blk = CausalSelfAttention(cfg["n_embd"], cfg["n_head"], n_query_groups=cfg["n_query_groups"], attn_alg=alg).to(torch.bfloat16)
+    torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
+    blk.quantize_base().cuda()
+    T = 640
+    cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    x0 = torch.randn(2, T, cfg["n_embd"], device="cuda", dtype=torch.bfloat16)
+    gy = torch.randn(2, T, cfg["n_embd"], device="cuda", dtype=torch.bfloat16)
+    res = []
+    for views in (True, False):
+        blk.group_views = views
+        for p in blk.parameters():
+            p.grad = None
+        if train:
+            x = x0.clone().requires_grad_(True)
+            y = blk(x, cos, sin)
+            y.backward(gy)
+            res.append((y.detach(), x.grad, blk.attn.lora_A.grad.clone(), blk.attn.lora_B.grad.clone()))
+        else:
+            with torch.no_grad():
+                res.append((blk(x0, cos, sin),))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_rope_split_group_views_are_views():
+    from fastmax_experiments_amd import ops
+    from fastmax_experiments_amd.attention_block import build_rope_cache
+    B, T, G, rep, hs = 2, 70, 3, 4, 64
+    qkv = torch.randn(B, T, G, rep + 2, hs, device="cuda", dtype=torch.bfloat16)
+    cos, sin = build_rope_cache(T, hs, device="cuda")
+    q1, k1, v1 = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 1)
+    q3, k3, v3 = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 3)
+    assert q3.shape == k3.shape == v3.shape == (B * G, rep, T, hs) and k3.stride(1) == 0 and v3.stride(1) == 0
+    assert torch.equal(q3.reshape(B, G * rep, T, hs), q1) and torch.equal(k3.reshape(B, G * rep, T, hs), k1)
+    assert torch.equal(v3.reshape(B, G * rep, T, hs), v1)
+    assert k3.untyped_storage().nbytes() == B * G * T * hs * 2          # one copy per key head, not per query head
+    _, k4, v4 = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 4)
+    assert k4.shape == (B, G, T, hs) and v4.stride(1) == 0

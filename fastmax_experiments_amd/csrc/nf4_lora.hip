@@ -43,8 +43,14 @@ struct Nf4Scale {
     const float* code2;       // dq: 256-entry map
     float offset;
     __device__ __forceinline__ float operator[](int64_t blk) const {
-        // product and sum rounded separately (no fused multiply-add): bit-identical to the host codec (lora.py)
-        return q ? __fadd_rn(__fmul_rn(code2[q[blk]], absmax2[blk >> 8]), offset) : absmax[blk];
+        return q ? mul_then_add(code2[q[blk]], absmax2[blk >> 8], offset) : absmax[blk];
+    }
+    // product and sum rounded separately: bit-identical to the host codec (lora.py).  hipcc contracts a * b + c into a
+    // fused multiply-add by default, and __fmul_rn / __fadd_rn are plain operators on this target
+    static __device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+        const float prod = a * b;
+        return prod + c;
     }
 };
 

@@ -17,6 +17,7 @@ torch.manual_seed(0)
 blk = CausalSelfAttention(n_embd, n_head, n_query_groups=groups, attn_alg=alg).to(torch.bfloat16)
 torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
 blk.quantize_base().cuda()
+blk.group_views = os.environ.get("FASTMAX_GROUP_VIEWS", "1") != "0"      # 0: the reference's expand, materialised (A/B)
 cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
 x = torch.randn(B, T, n_embd, device="cuda", dtype=torch.bfloat16, requires_grad=True)
 gy = torch.randn(B, T, n_embd, device="cuda", dtype=torch.bfloat16)

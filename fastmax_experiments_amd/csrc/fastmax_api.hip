@@ -141,7 +141,8 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
 size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
     const size_t a = bwd_quadratic_workspace(*prob), b = lin_bwd_workspace(*prob);
-    return a > b ? a : b;
+    const size_t c = scan_bwd_supported(*prob) ? scan_bwd_workspace(*prob) : 0;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 size_t fastmax_hip_forward_state_bytes(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
@@ -181,6 +182,9 @@ int fastmax_hip_backward_with_states(const fastmax_problem* prob, const void* q,
     const bool lin = prob->path != FASTMAX_PATH_QUADRATIC_MFMA && lin_bwd_supported(*prob) && prob->in_dtype == prob->out_dtype &&
                      !(reinterpret_cast<uintptr_t>(o) & 15);
     if (lin) return launch_bwd_lin(a);
+    // fp32 / fp16 at 64 < D <= 128: the same scans with two-part operands, one per gradient (fastmax_scan_d128_2p.hip)
+    if (prob->path != FASTMAX_PATH_QUADRATIC_MFMA && scan_bwd_supported(*prob) && !(reinterpret_cast<uintptr_t>(o) & 15))
+        return launch_bwd_scan(a);
     return quad32_bwd_supported(*prob) ? launch_bwd_quad32(a) : launch_bwd_quad_mfma(a);
 }
 

@@ -145,6 +145,9 @@ int launch_bwd_quad32(const BwdArgs& a);
 int launch_bwd_quad32_main(const BwdArgs& a);
 bool quad32_bwd_supported(const fastmax_problem& p);
 int launch_bwd_lin(const BwdArgs& a);
+int launch_bwd_scan(const BwdArgs& a);
+bool scan_bwd_supported(const fastmax_problem& p);
+size_t scan_bwd_workspace(const fastmax_problem& p);
 bool lin_bwd_supported(const fastmax_problem& p);
 size_t bwd_quadratic_workspace(const fastmax_problem& p);
 int launch_normalize(const void* x, Strides3 xs, int dtype, float* y, float* inv_norm, int B, int H, int N, int D,

@@ -324,7 +324,7 @@ def test_sequence_split_for_few_heads(shape, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_BWD), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
-@pytest.mark.parametrize("shape", [(2, 3, 640, 64), (1, 2, 1000, 32), (1, 2, 513, 48), (1, 1, 2048, 64), (1, 2, 777, 128),
+@pytest.mark.parametrize("shape", [(2, 3, 640, 64), (1, 2, 1000, 32), (1, 2, 513, 48), (1, 1, 2048, 64), (1, 2, 777, 128), (1, 1, 2100, 128),
                                    (2, 2, 1024, 96)])
 def test_linear_time_backward(shape, dt, tol):
     """p=1 masked backward by forward / reverse scans with carried state vs the C oracle and vs the tile kernels"""

@@ -27,7 +27,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_forward_state_bytes", "fastmax_hip_backward_with_states",
            "fastmax_hip_lora_scatter", "fastmax_hip_lora_scatter_backward",
            "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand", "fastmax_hip_tune",
-           "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s"]
+           "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s",
+           "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed"]
 
 
 class Problem(ctypes.Structure):
@@ -110,6 +111,10 @@ def lib():
     L.fastmax_hip_nf4_linear_backward_input_s.restype = ci
     L.fastmax_hip_nf4_dequantize_s.argtypes = [vp, vp, vp, i64, ci, vp]
     L.fastmax_hip_nf4_dequantize_s.restype = ci
+    L.fastmax_hip_qlora_gemm.argtypes = [vp, i64, vp, ci, vp, vp, vp, vp, ci, vp, i64, ci, ci, ci, vp]
+    L.fastmax_hip_qlora_gemm.restype = ci
+    L.fastmax_hip_nf4_dequantize_transposed.argtypes = [vp, vp, vp, ci, ci, vp]
+    L.fastmax_hip_nf4_dequantize_transposed.restype = ci
     L.fastmax_hip_lora_down.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, ci, vp]
     L.fastmax_hip_lora_down.restype = ci
     L.fastmax_hip_lora_tn_workspace.argtypes = [ci, ci, ci]

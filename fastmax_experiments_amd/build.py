@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfastmax_hip.so")
 SOURCES = ["fastmax_api.hip", "fastmax_generic.hip", "fastmax_normalize.hip", "fastmax_rope.hip", "fastmax_ce.hip", "fastmax_mfma.hip", "fastmax_mfma_v2.hip", "fastmax_mfma_gen.hip", "fastmax_mfma_bf16.hip", "fastmax_mfma_d128_2p.hip", "fastmax_scan_d128_2p.hip", "fastmax_mfma_split.hip", "fastmax_quad_mfma.hip",
-    "fastmax_quad32_mfma.hip", "fastmax_quad_mfma_bwd.hip", "fastmax_quad32_bwd.hip", "fastmax_mfma_bwd_lin.hip", "fastmax_decode.hip", "nf4_lora.hip", "lora_thin.hip"]
+    "fastmax_quad32_mfma.hip", "fastmax_quad_mfma_bwd.hip", "fastmax_quad32_bwd.hip", "fastmax_mfma_bwd_lin.hip", "fastmax_decode.hip", "nf4_lora.hip", "nf4_gemm.hip", "lora_thin.hip"]
 HEADERS = ["fastmax_common.h", "fastmax_mfma_common.h", "fastmax_mfma32_common.h", os.path.join("..", "..", "include", "fastmax_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
 

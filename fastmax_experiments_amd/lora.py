@@ -301,6 +301,15 @@ class _QLoRALinearFn(torch.autograd.Function):
         dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
         ctx.dense = dt == _lib.BF16 and (M >= DENSE_M or wdense is not None)
         ctx.wdense = wdense
+        ctx.hip_gemm = ctx.dense and QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0 and \
+            (ea is None or ea.shape[1] in (16, 32))
+        if ctx.hip_gemm:
+            # every product in libfastmax_hip.so: HIP decode into the scratch + the 256 x 256-tile GEMM (bias and the LoRA
+            # branch fused as its last step)
+            y = hip_gemm(x2, wdense if wdense is not None else _dense_weight(wq, scales, N, K), None, bias, ea, eb, N)
+            ctx.save_for_backward(ea, eb, wq)
+            ctx.dims = (M, N, K, dt)
+            return y
         if ctx.dense:
             y = x2 @ (wdense if wdense is not None else _dense_weight(wq, scales, N, K)).t()
             if ea is not None:
@@ -328,7 +337,9 @@ class _QLoRALinearFn(torch.autograd.Function):
         M, N, K, dt = ctx.dims
         dy = dy.contiguous()
         dx = d_ea = d_eb = None
-        if ctx.needs_input_grad[0] and ctx.dense:
+        if ctx.needs_input_grad[0] and ctx.hip_gemm:
+            dx = hip_gemm(dy, _dense_weight_t(wq, scales, N, K), None, None, None, None, K)
+        elif ctx.needs_input_grad[0] and ctx.dense:
             dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, scales, N, K))
         elif ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
@@ -434,6 +445,89 @@ class _ScatterRowsFn(torch.autograd.Function):
         return dB, None, None, None, None, None, None
 
 
+# How the frozen product runs at training row counts (M >= DENSE_M, bf16):
+#   "gemm"    (default) hand-written 256 x 256-tile GEMM (csrc/nf4_gemm.hip) on the weight decoded ONCE per call into a bf16
+#             scratch by a HIP kernel, bias and the LoRA branch fused into the GEMM (one more 32-deep step); dx through the same
+#             kernel on W^T (decoded transposed).  Measured (profiles/r02_qlora_gemm.md): 9-33 % faster than the library route
+#   "fused"   the same kernel with the NF4 codes decoded INSIDE its loop (no scratch): wins only where M / 256 is small --
+#             every 256-row block re-decodes the weight tile and the decode shares the vector ALU / LDS with the fragments
+#   "library" decode once + hipBLASLt through torch.matmul + the rank-r streaming kernels (round 1's route; kept for A/B)
+QLORA_ROUTE = os.environ.get("FASTMAX_QLORA_ROUTE", "gemm")
+
+
+def hip_gemm(x2: torch.Tensor, w: torch.Tensor, scales, bias, ea, eb, N: int) -> torch.Tensor:
+    """y (M, N) = x2 (M, K) w^T + bias + ea (M, RP) eb (N, RP)^T in libfastmax_hip.so; w: dense bf16 (N, K) when ``scales`` is
+    None, else the packed NF4 codes of an (N, K) weight with their block scales (decoded inside the kernel's loop)."""
+    M, K = x2.shape
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device):
+        rc = _lib.lib().fastmax_hip_qlora_gemm(x2.data_ptr(), x2.stride(0), w.data_ptr(), 0 if scales is None else 1,
+                                               None if scales is None else scales.ref, None if bias is None else bias.data_ptr(),
+                                               None if ea is None else ea.data_ptr(), None if eb is None else eb.data_ptr(),
+                                               0 if ea is None else ea.shape[1], y.data_ptr(), y.stride(0), M, N, K,
+                                               _stream(x2.device))
+    _lib.check(rc, "fastmax_hip_qlora_gemm")
+    return y
+
+
+_dense_scratch_t = {}
+
+
+def _dense_weight_t(wq, scales, N, K):
+    """bf16 (K, N) = W^T decoded from the codes of W (N, K) into a per-(device, stream) scratch (the operand of dx = dy W)"""
+    key = (wq.device, torch.cuda.current_stream(wq.device).cuda_stream)
+    buf = _dense_scratch_t.get(key)
+    if buf is None or buf.numel() < N * K:
+        buf = torch.empty(N * K, dtype=torch.bfloat16, device=wq.device)
+        _dense_scratch_t[key] = buf
+    with torch.cuda.device(wq.device):
+        rc = _lib.lib().fastmax_hip_nf4_dequantize_transposed(wq.data_ptr(), scales.ref, buf.data_ptr(), N, K, _stream(wq.device))
+    _lib.check(rc, "fastmax_hip_nf4_dequantize_transposed")
+    return buf[: N * K].view(K, N)
+
+
+class _QLoRAGemmFn(torch.autograd.Function):
+    """y = x deq(W)^T + bias + (x A^T) eb^T with every product in libfastmax_hip.so (lit_gpt/lora.py:170-177, 419-433 and
+    their autograd mirror, without dropout): the frozen product and dx by the 256 x 256-tile GEMM with the LoRA branch as
+    its last step, x A^T / dy eb by lora_down, dA / dB by lora_tn."""
+
+    @staticmethod
+    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused):
+        R, RP = A.shape[0], ebt.shape[0]
+        ctx.scales = scales
+        if R == RP:
+            abt = A.detach().to(torch.bfloat16).contiguous()
+        else:
+            abt = torch.zeros((RP, K), dtype=torch.bfloat16, device=x2.device)
+            abt[:R] = A.detach()
+        ea, eat = lora_down(x2, abt)
+        eb = ebt.t().contiguous()                                  # (N, RP): the B-side operand of the GEMM's last step
+        if fused and wdense is None:
+            y = hip_gemm(x2, wq, scales, bias, ea, eb, N)
+        else:
+            y = hip_gemm(x2, wdense if wdense is not None else _dense_weight(wq, scales, N, K), None, bias, ea, eb, N)
+        ctx.save_for_backward(x2, eat, abt, ebt, wq)
+        ctx.dims = (N, K, R, A.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, eat, abt, ebt, wq = ctx.saved_tensors
+        N, K, R, a_dt = ctx.dims
+        dy = dy.contiguous()
+        dx = dA = d_ebt = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_ea, d_eat = lora_down(dy, ebt)
+        if ctx.needs_input_grad[0]:
+            # dx = dy W + d_ea abt: the GEMM over n with W^T as its weight operand and the LoRA step (d_ea, abt^T)
+            dx = hip_gemm(dy, _dense_weight_t(wq, ctx.scales, N, K), None, None, d_ea, abt.t().contiguous(), K)
+        if ctx.needs_input_grad[1]:
+            dA = lora_tn(d_eat, x2, R, a_dt)
+        if ctx.needs_input_grad[2]:
+            d_ebt = lora_tn(eat, dy, dtype=torch.bfloat16)
+        return dx, dA, d_ebt, None, None, None, None, None, None, None
+
+
 class _QLoRAThinFn(torch.autograd.Function):
     """The many-rows route with the LoRA branch in libfastmax_hip.so: y = x deq(W)^T + bias + (x A^T) eb^T.
     Base products are library GEMMs on the decoded (or cached) weight; the rank-r products are lora_down / lora_tn / lora_up,
@@ -494,7 +588,11 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, NF4Scales(base.weight.quant_state), bias, N, K, base._dense_cache)
+    scales = NF4Scales(base.weight.quant_state)
+    if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
+        y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused")
+    else:
+        y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -512,7 +610,12 @@ def qlora_linear(x, base: NF4Linear, ea, eb):
     if ea is not None:
         r = ea.shape[-1]
         library_route = cdt == torch.bfloat16 and (x2.shape[0] >= DENSE_M or base._dense_cache is not None)
-        if library_route:
+        if library_route and QLORA_ROUTE != "library" and r <= 32:
+            # decode-once route on the hand-written GEMM: the branch is its last step, rank padded to 16 or 32
+            rp = _pad_rank(r)
+            ea = F.pad(ea.reshape(-1, r).to(torch.bfloat16), (0, rp - r)).contiguous()
+            eb = F.pad(eb.to(torch.bfloat16), (0, rp - r)).contiguous()
+        elif library_route:
             # decode-once / cached route: the LoRA branch is a plain addmm -- no padding to the fused kernel's 32-wide k-step
             ea, eb = ea.reshape(-1, r).to(torch.bfloat16), eb.to(torch.bfloat16)
         else:

@@ -260,6 +260,20 @@ int fastmax_hip_nf4_linear_backward_input_s(const void* dy, int64_t lddy, const 
 int fastmax_hip_nf4_dequantize_s(const uint8_t* wq, const fastmax_nf4_scales* scales, void* out, int64_t n, int dtype,
                                  void* stream);
 
+/* ---- QLoRA linear at training row counts, one kernel (csrc/nf4_gemm.hip): 256 x 256 output tiles, x by LDS-DMA, the frozen
+ *      weight decoded from NF4 in the loop (w_is_nf4 != 0, `scales` as above) or read as a dense bf16 (N, K) matrix
+ *      (w_is_nf4 == 0: a LoRALinear on a dense base, lit_gpt/lora.py:170-177), the LoRA branch as one more 32-deep step:
+ *        y[M][N] = x[M][K] . W[N][K]^T + bias[N] + ea[M][rank_pad] . eb[N][rank_pad]^T       (bf16 in / out, fp32 accumulate)
+ *      Needs K % 64 == 0, N % 8 == 0, 16-byte aligned rows; rank_pad 16 or 32; bias float32 or NULL; ea, eb both or neither. */
+int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_nf4, const fastmax_nf4_scales* scales,
+                           const float* bias, const void* ea, const void* eb, int rank_pad, void* y, int64_t ldy,
+                           int M, int N, int K, void* stream);
+
+/*      W^T as dense bf16 [K][N] from the codes of W [N][K]: the weight operand of dx = dy . W through fastmax_hip_qlora_gemm
+ *      (x := dy, w := W^T, M x K output).  N % 64 == 0, K % 64 == 0.                                                       */
+int fastmax_hip_nf4_dequantize_transposed(const uint8_t* wq, const fastmax_nf4_scales* scales, void* out, int N, int K,
+                                          void* stream);
+
 /* ---- QLoRA linear at training sizes: the rank-r products around the library GEMM of the frozen weight
  *      (csrc/lora_thin.hip).  Replaces the tensor ops of lit_gpt/lora.py:170-177 / :419-433 and their autograd mirror
  *      when the base product runs as a dense GEMM.  All matrices bf16 row-major, leading dimensions in elements,

@@ -336,3 +336,59 @@ def test_qlora_layer_with_double_quantised_base():
         assert _rel(y, _dense_reference(layer, x.detach())) < 2e-2
         y.backward(torch.randn_like(y))
         assert torch.isfinite(layer.lora_A.grad).all() and layer.linear.weight.grad is None
+
+
+@pytest.mark.parametrize("M,N,K,rp", [(2048, 2560, 2048, 16), (300, 320, 128, 32), (1000, 64, 448, 16), (513, 1096, 192, 0)])
+@pytest.mark.parametrize("dq", [False, True])
+def test_hand_written_qlora_gemm(M, N, K, rp, dq):
+    """csrc/nf4_gemm.hip (256 x 256 tiles, x by LDS-DMA, bias + LoRA step fused): dense bf16 weight and NF4 codes decoded in
+    the loop, ragged M / N included, against float32 math on the same dequantised weight; and the transposed dequantise."""
+    from fastmax_experiments_amd import lora
+    g = torch.Generator().manual_seed(M + N + K)
+    lin = torch.nn.Linear(K, N)
+    torch.nn.init.normal_(lin.weight, std=0.05, generator=g)
+    q = lora.NF4Linear.from_linear(lin, double_quant=dq).cuda()
+    scales = lora.NF4Scales(q.weight.quant_state)
+    wd = q.dequantize(torch.bfloat16)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    ea = eb = None
+    ref = x.float() @ wd.float().T + q.bias.float()
+    if rp:
+        ea = (torch.randn(M, rp, generator=g) * 0.1).to(torch.bfloat16).cuda()
+        eb = (torch.randn(N, rp, generator=g) * 0.1).to(torch.bfloat16).cuda()
+        ref = ref + ea.float() @ eb.float().T
+    y_dense = lora.hip_gemm(x, wd, None, q.bias, ea, eb, N)
+    y_nf4 = lora.hip_gemm(x, q.weight.data, scales, q.bias, ea, eb, N)
+    assert y_dense.shape == (M, N) and _rel(y_dense, ref) < 1e-2 and _rel(y_nf4, ref) < 1e-2
+    assert torch.equal(y_dense, y_nf4)                      # same bf16 weight values either way -> the same bits
+    if N % 64 == 0 and K % 64 == 0:
+        wt = lora._dense_weight_t(q.weight.data, scales, N, K)
+        assert torch.equal(wt, wd.t())
+
+
+@pytest.mark.parametrize("route", ["gemm", "fused", "library"])
+def test_training_size_qlora_layer_routes_agree(route, monkeypatch):
+    """LoRAQKVLinear at a training row count through the three routes of the frozen product (hand-written GEMM on the decoded
+    weight -- the default --, NF4 decoded inside the GEMM loop, decode once + library GEMM): forward and all gradients against
+    dense float32 math"""
+    from fastmax_experiments_amd import lora
+    monkeypatch.setattr(lora, "QLORA_ROUTE", route)
+    torch.manual_seed(7)
+    layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=(True, False, True))
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda()
+    lora.mark_only_lora_as_trainable(layer)
+    x = torch.randn(3, 1000, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)      # 3000 rows >= DENSE_M
+    y = layer(x)
+    assert _rel(y, _dense_reference(layer, x.detach())) < 2e-2
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xa = x.detach().float().requires_grad_(True)
+    A = layer.lora_A.detach().float().requires_grad_(True)
+    B = layer.lora_B.detach().float().requires_grad_(True)
+    wd = layer.linear.dequantize(torch.float32)
+    after_A = F.linear(xa, A)
+    after_B = layer.conv1d(after_A.transpose(-2, -1), B.unsqueeze(-1)).transpose(-2, -1)
+    yr = xa @ wd.T + layer.linear.bias.float() + layer.zero_pad(after_B) * layer.scaling
+    yr.backward(gy.float())
+    assert _rel(x.grad, xa.grad) < 3e-2 and _rel(layer.lora_A.grad, A.grad) < 3e-2 and _rel(layer.lora_B.grad, B.grad) < 3e-2

@@ -57,6 +57,9 @@ def main():
         ("C5 linearmax 16k fwd+bwd", "linearmax", (1, 32, 16384, 128), "bf16", 1, "fwd+bwd"),
         ("headline bf16 p=1 fwd+bwd", "fastmax", (16, 32, 4096, 64), "bf16", 1, "fwd+bwd"),
         ("headline p=2 fwd+bwd f32", "fastmax", (16, 32, 4096, 64), "f32", 2, "fwd+bwd"),
+        ("C4 heads fastmax p=1 f32 fwd+bwd (scan backward)", "fastmax", (2, 32, 4096, 128), "f32", 1, "fwd+bwd"),
+        ("C5 heads fastmax p=1 f32 16k fwd+bwd (scan backward)", "fastmax", (1, 32, 16384, 128), "f32", 1, "fwd+bwd"),
+        ("C5 heads linearmax f32 16k fwd+bwd", "linearmax", (1, 32, 16384, 128), "f32", 1, "fwd+bwd"),
     ]
     if quick:
         cases = cases[:4]

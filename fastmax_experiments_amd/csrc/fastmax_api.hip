@@ -52,7 +52,7 @@ struct TuneEntry { const char* name; const char* env; int value; };
 TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_variant", "FASTMAX_MFMA_VARIANT", 200},    // headline forward kernel: 200 = second generation (fastmax_mfma_v2.hip)
     {"bf16_kernel", "FASTMAX_BF16_KERNEL", 1},
-    {"gemm_sched", "FASTMAX_GEMM_SCHED", 2},          // QLoRA GEMM: vector instructions per matrix instruction in the decode steps
+    {"gemm_sched", "FASTMAX_GEMM_SCHED", 0},          // QLoRA GEMM: vector instructions per matrix instruction in the decode steps
 };
 bool g_tune_loaded = false;
 void tune_load() {

@@ -65,7 +65,10 @@ constexpr int LUT = 2 * STAGE;                                               // 
 constexpr int LDS_BYTES = LUT + 64;                                          // 131136
 }  // namespace g256
 
-template <bool WNF4, bool HALVES>
+// PF (dense weight only): every thread touches one 128-byte line of tile kt+2 (x rows / W rows) with a plain load that nobody
+// waits for, so the LDS-DMA of that tile, issued a step later, is served from L2 instead of HBM; the loop then waits with a
+// counted vmcnt (the prefetch stays in flight across the raw s_barrier) instead of the vmcnt(0) a __syncthreads() implies.
+template <bool WNF4, bool HALVES, bool PF = false>
 __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,6 +154,14 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, 0, smem + XT);
     }
     __syncthreads();
+    // PF: the line this thread touches in every tile (threads 0..255: x row, 256..511: W row)
+    unsigned int pf_sink = 0;
+    const char* pf_base = nullptr;
+    if constexpr (PF) {
+        const int prow = tid & 255;
+        pf_base = tid < 256 ? reinterpret_cast<const char*>(prm.x + (int64_t)min(m0 + prow, M - 1) * prm.ldx)
+                            : reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(prm.w) + (int64_t)min(n0 + prow, N - 1) * K);
+    }
     for (int kt = 0; kt < KT; ++kt) {
         char* cur = smem + (kt & 1) * STAGE;
         char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
@@ -158,6 +169,11 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         if (more) {
             dma_tile(prm.x, prm.ldx, m0, M, (kt + 1) * BK, nxt);
             if constexpr (!WNF4) dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 1) * BK, nxt + XT);
+        }
+        if constexpr (PF) {
+            // younger than the DMAs above on purpose: vmcnt(1) at the end of the step waits for them and not for this
+            const char* pa = pf_base + (int64_t)min(kt + 2, KT - 1) * (BK * 2);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pa) : "memory");
         }
         if constexpr (WNF4) {
             // The decode of tile kt+1 (its codes were fetched a step ago) is vector + LDS work, the 64 MFMAs of tile kt are
@@ -180,7 +196,18 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             mma_k32(cur, cur + XT, 0);
             mma_k32(cur, cur + XT, 1);
         }
-        __syncthreads();                                             // tile kt+1 landed (DMA drained by the barrier's wait), tile kt consumed
+        if constexpr (PF) {
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");         // this wave's DMAs of tile kt+1 landed; the prefetch may still fly
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __syncthreads();                                         // tile kt+1 landed (DMA drained by the barrier's wait), tile kt consumed
+        }
+    }
+    if constexpr (PF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(pf_sink));
     }
     // ---- LoRA branch: one more step over the padded rank ------------------------------------------------------------------
     if (prm.ea && prm.eb) {
@@ -206,17 +233,19 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     }
     // ---- epilogue: tile -> LDS as [256 m][256 n] bf16 (512-byte rows, 16-byte chunk index XOR-ed with m & 31), then rows out ---
     char* ct = smem;
+    gf32x4 bias4[4];                                                 // the lane's four columns of every column tile, fetched once
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int gn = min(n0 + 64 * wn + 16 * nt + 4 * q4, N - 4);
+        bias4[nt] = prm.bias ? *reinterpret_cast<const gf32x4*>(prm.bias + gn) : gf32x4{0, 0, 0, 0};
+    }
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int m = 128 * wm + 16 * mt + r;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = 64 * wn + 16 * nt + 4 * q4;                // 4 consecutive columns = 8 bytes
-            gf32x4 v = acc[nt][mt];
-            if (prm.bias) {
-                const int gn = min(n0 + n, N - 4);
-                v += *reinterpret_cast<const gf32x4*>(prm.bias + gn);
-            }
+            const gf32x4 v = acc[nt][mt] + bias4[nt];
             gbf16x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
@@ -266,9 +295,9 @@ __global__ __launch_bounds__(256) void nf4_dequant_transposed_kernel(const uint8
     }
 }
 
-template <bool WNF4, bool HALVES>
+template <bool WNF4, bool HALVES, bool PF = false>
 static int launch_gemm256(const GemmParams& p, hipStream_t stream) {
-    auto kern = qlora_gemm256_kernel<WNF4, HALVES>;
+    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
@@ -308,9 +337,11 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, sc, bias, reinterpret_cast<const __bf16*>(ea),
                  reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!w_is_nf4) return launch_gemm256<false, false>(p, st);
-    // A/B knob "gemm_sched": 0 = every wave decodes after its matrix instructions, else the two halves in opposite order
-    return tune_get(TUNE_GEMM_SCHED) == 0 ? launch_gemm256<true, false>(p, st) : launch_gemm256<true, true>(p, st);
+    // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
+    if (!w_is_nf4) return tune_get(TUNE_GEMM_SCHED) == 5 ? launch_gemm256<false, false, true>(p, st) : launch_gemm256<false, false, false>(p, st);
+    // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else
+    // every wave decodes after its matrix instructions
+    return tune_get(TUNE_GEMM_SCHED) == 1 ? launch_gemm256<true, true>(p, st) : launch_gemm256<true, false>(p, st);
 }
 
 // W^T [K][N] bf16 from the NF4 codes of W [N][K] (N % 64 == 0, K % 64 == 0, 16-byte aligned)

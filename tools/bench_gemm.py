@@ -69,8 +69,11 @@ def main():
         row("library: x @ Wd^T (weight already dense)", lambda: x @ wd.t())
         row("library route: decode once + x @ Wd^T + addmm(ea, eb) + bias",
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
-        row("hand-written, dense bf16 W (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb), lambda: gemm(x, wd, None, q.bias, ea, eb))
-        for sched, label in ((0, "every wave decodes after its MFMAs"), (1, "SIMD partner waves in opposite order")):
+        for sched, label in ((4, "__syncthreads per step"), (1, "L2 prefetch of tile t+2, counted waits")):
+            _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
+            row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
+                lambda: gemm(x, wd, None, q.bias, ea, eb))
+        for sched, label in ((0, "every wave decodes after its MFMAs"),):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, NF4 decoded in the loop, {label} (+ bias + LoRA step)",
                 lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb), lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb))

@@ -68,7 +68,9 @@ constexpr int LDS_BYTES = LUT + 64;                                          // 
 // PF (dense weight only): every thread touches one 128-byte line of tile kt+2 (x rows / W rows) with a plain load that nobody
 // waits for, so the LDS-DMA of that tile, issued a step later, is served from L2 instead of HBM; the loop then waits with a
 // counted vmcnt (the prefetch stays in flight across the raw s_barrier) instead of the vmcnt(0) a __syncthreads() implies.
-template <bool WNF4, bool HALVES, bool PF = false>
+// ILV: the next tile's staging issued piece by piece BETWEEN the groups of matrix instructions (see mma_k32_with); measured
+// neutral to 5 % slower than issuing it in front of the step ("gemm_sched" 6, kept for A/B)
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false>
 __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,6 +131,32 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = gf32x4{0, 0, 0, 0};
 
+    // one LDS-DMA instruction (1 KB = 8 rows) of a tile: the j-th of this wave's four
+    auto dma_piece = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, char* dst, int j) {
+        const int row = 8 * (4 * w + j) + drow;
+        const int gr = min(row0 + row, nrows - 1);
+        const __bf16* src = base + (int64_t)gr * ld + k0 + 8 * dchunk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + (4 * w + j) * 1024), 16, 0, 0);
+    };
+    // a 32-deep step whose four groups of eight MFMAs are each followed by one piece of the NEXT tile's staging (an LDS-DMA
+    // instruction or one decoded code word): issued between the matrix instructions their cost hides in the matrix pipe's
+    // shadow; eight DMA issues in front of the step cost 500-1000 cycles of a 3500-cycle step (MI355X_MICROARCH.md: 60-185 each)
+    auto mma_k32_with = [&](const char* Xs, const char* Ws, int ks, auto&& between) {
+        gbf16x8 af[4], bfm[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const gbf16x8*>(Ws + gsw(64 * wn + 16 * t + r, 4 * ks + q4));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bfm[t] = *reinterpret_cast<const gbf16x8*>(Xs + gsw(128 * wm + 16 * t + r, 4 * ks + q4));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfm[mt], acc[nt][mt], 0, 0, 0);
+            between(nt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto mma_k32 = [&](const char* Xs, const char* Ws, int ks) {
         gbf16x8 af[4], bfm[8];
 #pragma unroll
@@ -162,6 +190,25 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         pf_base = tid < 256 ? reinterpret_cast<const char*>(prm.x + (int64_t)min(m0 + prow, M - 1) * prm.ldx)
                             : reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(prm.w) + (int64_t)min(n0 + prow, N - 1) * K);
     }
+    if constexpr (ILV) {
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+            const bool more = kt + 1 < KT;
+            const int k1 = (kt + 1) * BK;
+            __builtin_amdgcn_sched_barrier(0);
+            mma_k32_with(cur, cur + XT, 0, [&](int j) { if (more) dma_piece(prm.x, prm.ldx, m0, M, k1, nxt, j); });
+            if constexpr (WNF4) {
+                mma_k32_with(cur, cur + XT, 1, [&](int j) { if (more) decode_words(nxt + XT, j, j + 1); });
+                if (kt + 2 < KT) load_codes((kt + 2) * BK);
+            } else {
+                mma_k32_with(cur, cur + XT, 1, [&](int j) {
+                    if (more) dma_piece(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, k1, nxt + XT, j);
+                });
+            }
+            __syncthreads();
+        }
+    } else
     for (int kt = 0; kt < KT; ++kt) {
         char* cur = smem + (kt & 1) * STAGE;
         char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
@@ -295,9 +342,9 @@ __global__ __launch_bounds__(256) void nf4_dequant_transposed_kernel(const uint8
     }
 }
 
-template <bool WNF4, bool HALVES, bool PF = false>
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false>
 static int launch_gemm256(const GemmParams& p, hipStream_t stream) {
-    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF>;
+    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
@@ -338,7 +385,12 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
                  reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
-    if (!w_is_nf4) return tune_get(TUNE_GEMM_SCHED) == 5 ? launch_gemm256<false, false, true>(p, st) : launch_gemm256<false, false, false>(p, st);
+    const int sched = tune_get(TUNE_GEMM_SCHED);
+    if (!w_is_nf4) {
+        if (sched == 5) return launch_gemm256<false, false, true>(p, st);
+        return sched == 6 ? launch_gemm256<false, false, false, true>(p, st) : launch_gemm256<false, false, false>(p, st);
+    }
+    if (sched == 6) return launch_gemm256<true, false, false, true>(p, st);
     // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else
     // every wave decodes after its matrix instructions
     return tune_get(TUNE_GEMM_SCHED) == 1 ? launch_gemm256<true, true>(p, st) : launch_gemm256<true, false>(p, st);

@@ -43,15 +43,17 @@ def test_lora_mqa_gqa_pins(groups, out, ind, bshape):
                                          (True, True, True)])
 def test_conv1d_equivalence_and_dense_operand(n_head, enable_lora):
     C = 12
+    torch.manual_seed(n_head * 8 + sum(4 >> i for i, e in enumerate(enable_lora) if e))
     layer = lora.LoRAQKVLinear(C, 3 * C, n_head=n_head, n_query_groups=n_head, r=2, enable_lora=enable_lora)
     torch.nn.init.normal_(layer.lora_B)
     x = torch.randn((1, 1, C))
     a = F.linear(x, layer.lora_A).transpose(-2, -1)
     b = layer.lora_B.data.unsqueeze(-1)
     ref = F.conv1d(a, b, groups=sum(layer.enable_lora))
-    assert torch.allclose(ref, layer.conv1d(a, b))
+    # the layer's block-diagonal product sums in a different order than the grouped convolution: float32 rounding apart
+    assert torch.allclose(ref, layer.conv1d(a, b), atol=1e-6)
     layer.n_head = layer.n_query_groups + 1
-    assert torch.allclose(ref, layer.conv1d(a, b))
+    assert torch.allclose(ref, layer.conv1d(a, b), atol=1e-6)
     # the single dense operand the fused kernel consumes reproduces zero_pad(conv1d(.)) exactly
     after_A = F.linear(x, layer.lora_A)
     want = layer.zero_pad(layer.conv1d(after_A.transpose(-2, -1), b).transpose(-2, -1))

@@ -69,15 +69,16 @@ def main():
         row("library: x @ Wd^T (weight already dense)", lambda: x @ wd.t())
         row("library route: decode once + x @ Wd^T + addmm(ea, eb) + bias",
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
-        for sched, label in ((4, "__syncthreads per step"), (1, "L2 prefetch of tile t+2, counted waits")):
+        for sched, label in ((0, "staging issued in front of the step"), (6, "staging pieces between the MFMA groups")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))
-        for sched, label in ((0, "every wave decodes after its MFMAs"),):
+        for sched, label in ((0, "decode after the MFMAs"), (6, "decode words between the MFMA groups")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, NF4 decoded in the loop, {label} (+ bias + LoRA step)",
                 lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb), lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb))
-        row("hand-written pair: HIP decode to bf16 scratch + dense-W kernel (+ bias + LoRA step)",
+        _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", 6), "tune")
+        row("hand-written pair (sched 6): HIP decode to bf16 scratch + dense-W kernel (+ bias + LoRA step)",
             lambda: gemm(x, lora._dense_weight(q.weight.data, scales, N, K), None, q.bias, ea, eb))
 
 

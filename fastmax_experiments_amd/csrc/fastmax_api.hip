@@ -53,6 +53,7 @@ TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_variant", "FASTMAX_MFMA_VARIANT", 200},    // headline forward kernel: 200 = second generation (fastmax_mfma_v2.hip)
     {"bf16_kernel", "FASTMAX_BF16_KERNEL", 1},
     {"gemm_sched", "FASTMAX_GEMM_SCHED", 0},          // QLoRA GEMM: vector instructions per matrix instruction in the decode steps
+    {"gemm_group_m", "FASTMAX_GEMM_GROUP_M", 16},     // QLoRA / head GEMM: row blocks per group of the workgroup -> tile map (0: column blocks fastest over the whole matrix)
 };
 bool g_tune_loaded = false;
 void tune_load() {

@@ -48,6 +48,15 @@ struct GemmParams {
     int M, N, K, RP;          // RP: 16 or 32 (rank padded)
     int64_t ldx, ldy;
     int nbn;                  // number of 256-column blocks
+    int nbm, group_m;         // number of 256-row blocks; row blocks per group of the workgroup -> tile map (0: none)
+    // lm-head + cross entropy epilogues (EPI 1 / 2): the tile is a block of logits that never leaves the chip
+    const int64_t* targets;   // [M]
+    float* part;              // EPI 1: [M][nbn] (max, sum exp) of the row over this column block
+    float* ztgt;              // EPI 1: [M] the target's logit (written by the one lane that holds it)
+    const float* lse;         // EPI 2: [M] log sum exp of the row
+    float gscale;             // EPI 2: d(loss)/d(row loss)
+    int64_t ignore_index;
+    unsigned long long* stamps;   // diagnostics: [workgroup][2] = (shader cycles, 100 MHz ticks) of the main loop; null normally
 };
 
 __constant__ float kGemmNF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
@@ -70,7 +79,13 @@ constexpr int LDS_BYTES = LUT + 64;                                          // 
 // counted vmcnt (the prefetch stays in flight across the raw s_barrier) instead of the vmcnt(0) a __syncthreads() implies.
 // ILV: the next tile's staging issued piece by piece BETWEEN the groups of matrix instructions (see mma_k32_with); measured
 // neutral to 5 % slower than issuing it in front of the step ("gemm_sched" 6, kept for A/B)
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false>
+// EPI: what happens to the finished 256 x 256 tile.  0: stored (the linear layer).  1 / 2: the tile is a block of lm-head
+// logits z = x W^T, rounded to bf16 like the reference's head output, and consumed in registers --
+//   1 (loss forward) : per row the (max, sum exp) pair over the block's columns -> part[m][bn]; the target's logit -> ztgt[m]
+//   2 (loss backward): dz = (exp(z - lse_m) - [n == t_m]) * gscale (0 for rows that are not scored) stored as bf16
+//   3 (loss forward that keeps the logits for the backward pass): 1, then the tile stored as bf16 like 0
+// so the (tokens x vocabulary) logits are never written or read (lit_gpt/utils.py:228-272 after lora.py:547-550).
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false>
 __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,7 +96,16 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     const int r = lane & 15, q4 = lane >> 4;
     // workgroup -> tile: column blocks fastest, so the workgroups that land on one XCD (ids congruent mod 8) share a few
     // column blocks of W (they stay in that XCD's L2) and stream over the rows of x
-    const int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    // With many column blocks (the lm-head: 125) that order makes the 256 concurrent tiles two rows of blocks that stream ALL
+    // of W per pass; in groups of `group_m` row blocks, rows fastest, the concurrent tiles form a 16 x 16 patch instead
+    // (16 + 16 operand blocks per 256 tiles, not 2 + 125).
+    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    if (prm.group_m > 0) {
+        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
+        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
+        bm = grp * prm.group_m + rem % rows;
+        bn = rem / rows;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const int M = prm.M, N = prm.N, K = prm.K;
     if (WNF4 && tid < 16) lut[tid] = kGemmNF4[tid];
@@ -98,6 +122,23 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + (4 * w + j) * 1024), 16, 0, 0);
         }
+    };
+    // REG: the same tiles through registers instead -- four 16-byte loads per operand per thread at the start of a step, four
+    // ds_write_b128 into the swizzled image after the step's matrix instructions.  An LDS-DMA piece costs its wave 60-185
+    // issue cycles (MI355X_MICROARCH.md), 16 of them per SIMD and step against 2048 cycles of matrix work; a plain load and
+    // a ds_write_b128 cost ~4 + 13.
+    gu32x4 xs[4], wsr[4];
+    auto reg_load = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, gu32x4 (&rg)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 8 * (4 * w + j) + drow;
+            const int gr = min(row0 + row, nrows - 1);
+            rg[j] = *reinterpret_cast<const gu32x4*>(base + (int64_t)gr * ld + k0 + 8 * dslot);
+        }
+    };
+    auto reg_store = [&](char* dst, const gu32x4 (&rg)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<gu32x4*>(dst + gsw(8 * (4 * w + j) + drow, dslot)) = rg[j];
     };
     // ---- W tile from NF4 codes: thread -> row wrow, 32 codes of half whalf ----------------------------------------------
     const int wrow = tid >> 1, whalf = tid & 1;
@@ -170,7 +211,26 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfm[mt], acc[nt][mt], 0, 0, 0);
     };
 
+    // PIPE: the fragments of the next 32-deep half are read from LDS while the matrix instructions of the current half run.
+    // With "read 12 fragments, then 32 MFMAs" every wave leaves the step's barrier at the same moment, so all eight read LDS
+    // together and then all multiply together: neither unit overlaps the other (~3500 cycles per step against 2048 of MFMA).
+    auto read_frags = [&](const char* Xs, const char* Ws, int ks, gbf16x8 (&af)[4], gbf16x8 (&bfm)[8]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const gbf16x8*>(Ws + gsw(64 * wn + 16 * t + r, 4 * ks + q4));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bfm[t] = *reinterpret_cast<const gbf16x8*>(Xs + gsw(128 * wm + 16 * t + r, 4 * ks + q4));
+    };
+    auto mma_frags = [&](const gbf16x8 (&af)[4], const gbf16x8 (&bfm)[8]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfm[mt], acc[nt][mt], 0, 0, 0);
+    };
+
     const int KT = K / BK;
+    unsigned long long t0c = 0, t0r = 0;
+    if (prm.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
     // prologue: tile 0 -> stage 0; the codes of tile 1 wait in registers
     dma_tile(prm.x, prm.ldx, m0, M, 0, smem);
     if constexpr (WNF4) {
@@ -190,7 +250,71 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         pf_base = tid < 256 ? reinterpret_cast<const char*>(prm.x + (int64_t)min(m0 + prow, M - 1) * prm.ldx)
                             : reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(prm.w) + (int64_t)min(n0 + prow, N - 1) * K);
     }
-    if constexpr (ILV) {
+    if constexpr (PIPE) {
+        // fragments: the four weight fragments of a half are double-buffered (a0 / a1); the eight x fragments rotate in place --
+        // the loop runs row tile by row tile, and as soon as the four MFMAs of row tile mt have been issued b[mt] is refilled
+        // with the next half's fragment
+        gbf16x8 a0[4], a1[4], b[8];
+        auto half = [&](const gbf16x8 (&af)[4], gbf16x8 (&afn)[4], const char* nXs, const char* nWs, int nks, bool fetch) {
+            if (fetch) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afn[t] = *reinterpret_cast<const gbf16x8*>(nWs + gsw(64 * wn + 16 * t + r, 4 * nks + q4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                if (fetch) b[mt] = *reinterpret_cast<const gbf16x8*>(nXs + gsw(128 * wm + 16 * mt + r, 4 * nks + q4));
+            }
+        };
+        if (KT > 1) {
+            dma_tile(prm.x, prm.ldx, m0, M, BK, smem + STAGE);
+            if constexpr (!WNF4) dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, BK, smem + STAGE + XT);
+        }
+        read_frags(smem, smem + XT, 0, a0, b);
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+            const bool more = kt + 1 < KT;
+            half(a0, a1, cur, cur + XT, 1, true);
+            if constexpr (WNF4) {
+                if (more) decode_codes(nxt + XT);                    // nxt: last read (tile kt-1) before the previous barrier
+            }
+            __syncthreads();                                         // tile kt+1 whole in nxt; nobody reads cur any more
+            if (kt + 2 < KT) {
+                dma_tile(prm.x, prm.ldx, m0, M, (kt + 2) * BK, cur);
+                if constexpr (WNF4) load_codes((kt + 2) * BK);
+                else dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 2) * BK, cur + XT);
+            }
+            const char* nf = more ? nxt : cur;                       // last step: a harmless re-read instead of a branch per tile
+            half(a1, a0, nf, nf + XT, 0, true);
+        }
+        __syncthreads();
+    } else if constexpr (REG) {
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+            const bool more = kt + 1 < KT;
+            if (more) {
+                reg_load(prm.x, prm.ldx, m0, M, (kt + 1) * BK, xs);
+                if constexpr (!WNF4) reg_load(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 1) * BK, wsr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_k32(cur, cur + XT, 0);
+            mma_k32(cur, cur + XT, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                reg_store(nxt, xs);
+                if constexpr (!WNF4) reg_store(nxt + XT, wsr);
+            }
+            if constexpr (WNF4) {
+                if (more) decode_codes(nxt + XT);
+                if (kt + 2 < KT) load_codes((kt + 2) * BK);
+            }
+            __syncthreads();
+        }
+    } else if constexpr (ILV) {
         for (int kt = 0; kt < KT; ++kt) {
             char* cur = smem + (kt & 1) * STAGE;
             char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
@@ -256,6 +380,10 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::"v"(pf_sink));
     }
+    if (prm.stamps && tid == 0) {
+        prm.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        prm.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
     // ---- LoRA branch: one more step over the padded rank ------------------------------------------------------------------
     if (prm.ea && prm.eb) {
         // EA rows m0.. -> X image, EB rows n0.. -> W image (stage 0); RP = 16 or 32 columns = 2 or 4 chunks per row
@@ -278,6 +406,54 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         mma_k32(smem, smem + XT, 0);
         __syncthreads();
     }
+    if constexpr (EPI == 1 || EPI == 3) {
+        // ---- loss forward: nothing of the tile is stored (EPI 3: the reduction first, then the tile is stored as well).  Lane (r, q4) of wave (wm, wn) holds, for row 128 wm + 16 mt + r,
+        //      the 16 columns 64 wn + 16 nt + 4 q4 + i: reduce in the lane, across the four q4 lanes, then across the four wn waves
+        float2* red = reinterpret_cast<float2*>(smem);               // [256 m][4 wn]
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = 128 * wm + 16 * mt + r, gm = m0 + m;
+            const int64_t t = gm < M ? prm.targets[gm] : -1;
+            const int64_t tloc = t - n0 - 64 * wn;                    // the target's column inside this wave's 64, if any
+            float z[16], mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = 16 * nt + 4 * q4 + i;
+                    float v = (float)(__bf16)acc[nt][mt][i];
+                    if (n0 + 64 * wn + n >= N) v = -INFINITY;
+                    else if (n == tloc && t != prm.ignore_index) prm.ztgt[gm] = v;
+                    z[4 * nt + i] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+            if (mx > -INFINITY) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += __expf(z[e] - mx);
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (q4 == 0) red[m * 4 + wn] = make_float2(mx, sum);
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) {
+            float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 pr = red[tid * 4 + j];
+                const float mm = fmaxf(mx, pr.x);
+                const float a = sum > 0.f ? sum * __expf(mx - mm) : 0.f, b = pr.y > 0.f ? pr.y * __expf(pr.x - mm) : 0.f;
+                mx = mm;
+                sum = a + b;
+            }
+            reinterpret_cast<float2*>(prm.part)[(int64_t)(m0 + tid) * prm.nbn + bn] = make_float2(mx, sum);
+        }
+        if constexpr (EPI == 1) return;
+        __syncthreads();                                             // `red` is about to be overwritten by the tile image
+    }
     // ---- epilogue: tile -> LDS as [256 m][256 n] bf16 (512-byte rows, 16-byte chunk index XOR-ed with m & 31), then rows out ---
     char* ct = smem;
     gf32x4 bias4[4];                                                 // the lane's four columns of every column tile, fetched once
@@ -289,10 +465,26 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int m = 128 * wm + 16 * mt + r;
+        float row_lse = 0.f, row_scale = 0.f;
+        int64_t tloc = -1;
+        if constexpr (EPI == 2) {
+            const int gm = min(m0 + m, M - 1);
+            const int64_t t = prm.targets[gm];
+            row_lse = prm.lse[gm];
+            row_scale = (t != prm.ignore_index && t >= 0 && t < N) ? prm.gscale : 0.f;
+            tloc = t - n0;
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = 64 * wn + 16 * nt + 4 * q4;                // 4 consecutive columns = 8 bytes
-            const gf32x4 v = acc[nt][mt] + bias4[nt];
+            gf32x4 v = acc[nt][mt] + bias4[nt];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf((float)(__bf16)v[i] - row_lse) - ((n + i == tloc) ? 1.f : 0.f);
+                    v[i] = p * row_scale;
+                }
+            }
             gbf16x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
@@ -342,9 +534,25 @@ __global__ __launch_bounds__(256) void nf4_dequant_transposed_kernel(const uint8
     }
 }
 
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false>
-static int launch_gemm256(const GemmParams& p, hipStream_t stream) {
-    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV>;
+// rows of the fused head loss: the per-column-block (max, sum exp) pairs of a row -> its log-sum-exp and loss
+__global__ __launch_bounds__(256) void lmhead_ce_combine_kernel(const float* part, const float* ztgt, const int64_t* targets, float* loss,
+                                                                float* lse, int M, int V, int nbn, int64_t ignore_index) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float2* pr = reinterpret_cast<const float2*>(part) + (int64_t)m * nbn;
+    float mx = -INFINITY;
+    for (int b = 0; b < nbn; ++b) mx = fmaxf(mx, pr[b].x);
+    float sum = 0.f;
+    for (int b = 0; b < nbn; ++b) sum += pr[b].y > 0.f ? pr[b].y * __expf(pr[b].x - mx) : 0.f;
+    const float l = mx + __logf(sum);
+    const int64_t t = targets[m];
+    lse[m] = l;
+    loss[m] = (t != ignore_index && t >= 0 && t < V) ? l - ztgt[m] : 0.f;
+}
+
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false>
+static int launch_gemm256(GemmParams p, hipStream_t stream) {
+    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV, EPI, REG, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
@@ -352,6 +560,8 @@ static int launch_gemm256(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nbm = (p.M + 255) / 256;
+    p.nbm = nbm;
+    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;       // few column blocks: W stays in L2 whatever the order
     hipLaunchKernelGGL(kern, dim3(p.nbn * nbm), dim3(512), g256::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
@@ -360,7 +570,13 @@ static int launch_gemm256(const GemmParams& p, hipStream_t stream) {
 
 using namespace fastmax;
 
+static unsigned long long* g_gemm_stamps = nullptr;
+
 extern "C" {
+
+// diagnostics (tools/gemm_clock.py): a device buffer of 2 x (number of workgroups) 64-bit words that the next
+// fastmax_hip_qlora_gemm launches fill with the main loop's shader cycles and 100 MHz ticks per workgroup; null turns it off
+void fastmax_hip_debug_gemm_stamps(void* buffer) { g_gemm_stamps = reinterpret_cast<unsigned long long*>(buffer); }
 
 // y = x W^T (+ bias) (+ ea eb^T): W as NF4 codes with `scales` (w_is_nf4 != 0) or as a dense bf16 matrix (scales ignored).
 // bf16 activations; needs K % 64 == 0, N % 8 == 0, 16-byte aligned rows; rank_pad 16 or 32 when ea / eb are given.
@@ -382,10 +598,15 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
         sc = GemmScale{scales->absmax, scales->absmax_q, scales->absmax2, scales->code2, scales->offset};
     }
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, sc, bias, reinterpret_cast<const __bf16*>(ea),
-                 reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256};
+                 reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256, 0, 0,
+                 nullptr, nullptr, nullptr, nullptr, 0.f, 0, g_gemm_stamps};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
     const int sched = tune_get(TUNE_GEMM_SCHED);
+    if (sched == 8) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, true>(p, st)
+                                    : launch_gemm256<false, false, false, false, 0, false, true>(p, st);
+    if (sched == 7) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, true>(p, st)
+                                    : launch_gemm256<false, false, false, false, 0, true>(p, st);
     if (!w_is_nf4) {
         if (sched == 5) return launch_gemm256<false, false, true>(p, st);
         return sched == 6 ? launch_gemm256<false, false, false, true>(p, st) : launch_gemm256<false, false, false>(p, st);
@@ -394,6 +615,54 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else
     // every wave decodes after its matrix instructions
     return tune_get(TUNE_GEMM_SCHED) == 1 ? launch_gemm256<true, true>(p, st) : launch_gemm256<true, false>(p, st);
+}
+
+// ---- lm-head + cross entropy without the logits (finetune/lora.py:216-219 = GPT.forward's chunked head,
+//      lora.py:547-550, feeding chunked_cross_entropy, lit_gpt/utils.py:228-272).  x [M][K] bf16 hidden states, w [V][K] bf16
+//      head weight, targets [M] int64.  K % 64 == 0, V % 8 == 0, 16-byte aligned rows.
+int64_t fastmax_hip_lmhead_ce_workspace(int M, int V) {
+    if (M <= 0 || V <= 0) return 0;
+    return ((int64_t)M * ((V + 255) / 256) * 2 + M) * (int64_t)sizeof(float);
+}
+
+// loss[m] = logsumexp_v(z_mv) - z_m,t(m) with z = bf16(x W^T) (0 for rows that are not scored: ignore_index or outside [0, V));
+// lse[m] kept for the backward pass.  workspace: fastmax_hip_lmhead_ce_workspace(M, V) bytes.  `logits` non-null: the bf16
+// logits are stored as well ([M][V], leading dimension ldz) -- the backward pass then needs no second product (288 GB of HBM
+// hold them easily: 1 GB per 16384 x 32000), fastmax_hip_cross_entropy_backward in place + dx = dz . W.
+int fastmax_hip_lmhead_ce_forward(const void* x, int64_t ldx, const void* w, const int64_t* targets, float* loss, float* lse,
+                                  void* workspace, void* logits, int64_t ldz, int M, int V, int K, int64_t ignore_index,
+                                  void* stream) {
+    if (!x || !w || !targets || !loss || !lse || !workspace) return FASTMAX_E_NULL;
+    if (M <= 0 || V <= 0 || K <= 0 || (K % 64) || (V % 8)) return FASTMAX_E_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(workspace)) & 15) return FASTMAX_E_ALIGNMENT;
+    if ((ldx * 2) & 15) return FASTMAX_E_ALIGNMENT;
+    if (logits && ((reinterpret_cast<uintptr_t>(logits) & 15) || ((ldz * 2) & 15))) return FASTMAX_E_ALIGNMENT;
+    const int nbn = (V + 255) / 256;
+    float* part = reinterpret_cast<float*>(workspace);
+    float* ztgt = part + (int64_t)M * nbn * 2;
+    GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
+                 reinterpret_cast<__bf16*>(logits), M, V, K, 0, ldx, ldz, nbn, 0, 0, targets, part, ztgt, nullptr, 0.f, ignore_index,
+                 nullptr};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = logits ? launch_gemm256<false, false, false, false, 3>(p, st) : launch_gemm256<false, false, false, false, 1>(p, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lmhead_ce_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, ztgt, targets, loss, lse, M, V, nbn,
+                       ignore_index);
+    return (int)hipGetLastError();
+}
+
+// dz[m][v] = (exp(z_mv - lse[m]) - [v == t(m)]) * grad_scale as bf16 (rows that are not scored: 0), the logits recomputed in
+// the tile and never stored: dx = dz . W and (a trainable head's) dW = dz^T . x are plain matrix products of the result.
+int fastmax_hip_lmhead_ce_backward(const void* x, int64_t ldx, const void* w, const int64_t* targets, const float* lse,
+                                   float grad_scale, void* dz, int64_t ldz, int M, int V, int K, int64_t ignore_index, void* stream) {
+    if (!x || !w || !targets || !lse || !dz) return FASTMAX_E_NULL;
+    if (M <= 0 || V <= 0 || K <= 0 || (K % 64) || (V % 8)) return FASTMAX_E_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dz)) & 15) return FASTMAX_E_ALIGNMENT;
+    if (((ldx * 2) & 15) || ((ldz * 2) & 15)) return FASTMAX_E_ALIGNMENT;
+    GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
+                 reinterpret_cast<__bf16*>(dz), M, V, K, 0, ldx, ldz, (V + 255) / 256, 0, 0, targets, nullptr, nullptr, lse, grad_scale,
+                 ignore_index, nullptr};
+    return launch_gemm256<false, false, false, false, 2>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // W^T [K][N] bf16 from the NF4 codes of W [N][K] (N % 64 == 0, K % 64 == 0, 16-byte aligned)

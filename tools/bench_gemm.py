@@ -69,16 +69,18 @@ def main():
         row("library: x @ Wd^T (weight already dense)", lambda: x @ wd.t())
         row("library route: decode once + x @ Wd^T + addmm(ea, eb) + bias",
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
-        for sched, label in ((0, "staging issued in front of the step"), (6, "staging pieces between the MFMA groups")):
+        for sched, label in ((0, "LDS-DMA staging issued in front of the step"), (6, "LDS-DMA pieces between the MFMA groups"),
+                             (7, "staging through registers (load, MFMAs, ds_write)"),
+                             (8, "fragments of the next half read under the MFMAs of this one")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))
-        for sched, label in ((0, "decode after the MFMAs"), (6, "decode words between the MFMA groups")):
+        for sched, label in ((0, "decode after the MFMAs"), (6, "decode words between the MFMA groups"), (7, "x through registers"), (8, "fragments read under the MFMAs")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, NF4 decoded in the loop, {label} (+ bias + LoRA step)",
                 lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb), lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb))
-        _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", 6), "tune")
-        row("hand-written pair (sched 6): HIP decode to bf16 scratch + dense-W kernel (+ bias + LoRA step)",
+        _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", 0), "tune")
+        row("hand-written pair (sched 0): HIP decode to bf16 scratch + dense-W kernel (+ bias + LoRA step)",
             lambda: gemm(x, lora._dense_weight(q.weight.data, scales, N, K), None, q.bias, ea, eb))
 
 

@@ -1,0 +1,47 @@
+"""In-kernel clock and cycles per K step of the hand-written GEMM (diagnostic build path: stamps are written only when a
+buffer is registered).  For each "gemm_sched" variant: sustained launches for ~1 s, then one stamped launch.
+`python tools/gemm_clock.py [M N K]`"""
+import ctypes
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from fastmax_experiments_amd import _lib, lora  # noqa: E402
+
+
+def main():
+    M, N, K = (16384, 4096, 4096) if len(sys.argv) < 4 else tuple(int(a) for a in sys.argv[1:4])
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    L = _lib.lib()
+    L.fastmax_hip_debug_gemm_stamps.argtypes = [ctypes.c_void_p]
+    L.fastmax_hip_debug_gemm_stamps.restype = None
+    nwg = ((M + 255) // 256) * ((N + 255) // 256)
+    stamps = torch.zeros(nwg, 2, dtype=torch.int64, device="cuda")
+    for sched in (0, 6, 7, 8):
+        L.fastmax_hip_tune(b"gemm_sched", sched)
+        t_end = time.perf_counter() + 1.0
+        n = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                lora.hip_gemm(x, w, None, None, None, None, N)
+            n += 20
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        L.fastmax_hip_debug_gemm_stamps(stamps.data_ptr())
+        lora.hip_gemm(x, w, None, None, None, None, N)
+        torch.cuda.synchronize()
+        L.fastmax_hip_debug_gemm_stamps(None)
+        cyc = stamps[:, 0].double().median().item()
+        ticks = stamps[:, 1].double().median().item()
+        print(f"sched {sched}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.0f} TF/s; main loop {cyc:.0f} cycles = {cyc / (K // 64):.0f} per K step "
+              f"(matrix pipe: 2048); in-kernel clock {cyc / ticks * 0.1:.2f} GHz", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,7 @@ constexpr int LDS_BYTES = LUT + 64;                                          // 
 //   2 (loss backward): dz = (exp(z - lse_m) - [n == t_m]) * gscale (0 for rows that are not scored) stored as bf16
 //   3 (loss forward that keeps the logits for the backward pass): 1, then the tile stored as bf16 like 0
 // so the (tokens x vocabulary) logits are never written or read (lit_gpt/utils.py:228-272 after lora.py:547-550).
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false>
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false>
 __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,6 +114,21 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     const int drow = lane >> 3, dslot = lane & 7;
     const int dchunk = dslot ^ drow;                                 // the row's low three bits are drow (rows come in 8s)
     auto dma_tile = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, char* dst) {
+        if constexpr (SPEC) {
+            // only one wave of each SIMD pair (w < 4; w and w + 4 share a SIMD) issues the copies, eight pieces per operand:
+            // its partner goes straight to the matrix instructions, so the SIMD multiplies while the copies are being issued
+            if (w < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pc = 8 * w + j, row = 8 * pc + drow;
+                    const int gr = min(row0 + row, nrows - 1);
+                    const __bf16* src = base + (int64_t)gr * ld + k0 + 8 * dchunk;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * w + j) + drow;
@@ -550,9 +565,9 @@ __global__ __launch_bounds__(256) void lmhead_ce_combine_kernel(const float* par
     loss[m] = (t != ignore_index && t >= 0 && t < V) ? l - ztgt[m] : 0.f;
 }
 
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false>
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false>
 static int launch_gemm256(GemmParams p, hipStream_t stream) {
-    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV, EPI, REG, PIPE>;
+    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV, EPI, REG, PIPE, SPEC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
@@ -603,6 +618,10 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
     const int sched = tune_get(TUNE_GEMM_SCHED);
+    if (sched == 9) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, true>(p, st)
+                                    : launch_gemm256<false, false, false, false, 0, false, false, true>(p, st);
+    if (sched == 10) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, true, true>(p, st)
+                                     : launch_gemm256<false, false, false, false, 0, false, true, true>(p, st);
     if (sched == 8) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, true>(p, st)
                                     : launch_gemm256<false, false, false, false, 0, false, true>(p, st);
     if (sched == 7) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, true>(p, st)

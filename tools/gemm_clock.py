@@ -21,7 +21,7 @@ def main():
     L.fastmax_hip_debug_gemm_stamps.restype = None
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
     stamps = torch.zeros(nwg, 2, dtype=torch.int64, device="cuda")
-    for sched in (0, 6, 7, 8):
+    for sched in (0, 8, 9, 10):
         L.fastmax_hip_tune(b"gemm_sched", sched)
         t_end = time.perf_counter() + 1.0
         n = 0

@@ -111,9 +111,13 @@ def chunked_cross_entropy(logits: Union[torch.Tensor, List[torch.Tensor]], targe
 
 def _kept_backward(ctx, grad_out):
     """backward pass over kept bf16 / fp32 logits: the row kernel turns them into d(logits) in place, then two plain products"""
+    if getattr(ctx, "logits_consumed", False):
+        raise RuntimeError("second backward pass through lm_head_cross_entropy: the kept logits were turned into d(logits) in "
+                           "place by the first one (FASTMAX_HEAD_KEEP_BYTES=0 recomputes them instead)")
     x2d, weight, targets1d, lse, n, logits = ctx.saved_tensors
     scale = float(grad_out.float() / n)                                     # one host sync per backward (scalar loss)
     _rows_backward(logits, targets1d, lse, None, scale, ctx.ignore_index, logits)
+    ctx.logits_consumed = True
     dx = logits @ weight if ctx.needs_input_grad[0] else None
     dw = (logits.t() @ x2d) if ctx.needs_input_grad[1] else None
     return dx, dw, None, None, None, None

@@ -221,6 +221,22 @@ def rope_qkv_supported(dtype, head_size, rope_n_elem):
     return dtype in _DT and rope_n_elem % 2 == 0 and (rope_n_elem // 2) % e == 0 and (head_size - rope_n_elem) % e == 0
 
 
+_ROPE_F32 = {}
+
+
+def _rope_tables_f32(cos, sin, T, n_elem):
+    """the kernel's exact float32 copies of the first T rows of the rope cache; every layer of a step asks for the same
+    tables, so the last conversion is kept (keyed by storage, version and shape of the cache tensors)"""
+    key = (cos.data_ptr(), sin.data_ptr(), cos._version, sin._version, tuple(cos.shape), cos.dtype, str(cos.device), T, n_elem)
+    hit = _ROPE_F32.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    c = cos[:T, :n_elem].float().contiguous()
+    s_ = sin[:T, :n_elem].float().contiguous()
+    _ROPE_F32["last"] = (key, c, s_, cos, sin)          # the cache tensors are held so that their addresses cannot be reused
+    return c, s_
+
+
 class RopeQKVSplit(torch.autograd.Function):
     """qkv (B,T,G,q_per_kv+2,hs) -> q (B,H,T,hs), k, v (B,H,T,hs): de-interleave + RoPE + GQA expand in one HIP pass
     (fastmax_rope.hip; lit_gpt/model.py:397-425), and the mirror pass for the gradient."""
@@ -243,8 +259,7 @@ class RopeQKVSplit(torch.autograd.Function):
         # a rope cache kept in the tensors' own 16-bit dtype ("bf16-true"): model.py:708 then rounds each product to that
         # dtype before the sum -- the kernel reproduces those roundings (tables travel as exact float32 copies)
         tables16 = 16 if (cos.dtype == qkv.dtype and qkv.dtype in (torch.bfloat16, torch.float16)) else 0
-        cos = cos[:T, :rope_n_elem].float().contiguous()
-        sin = sin[:T, :rope_n_elem].float().contiguous()
+        cos, sin = _rope_tables_f32(cos, sin, T, rope_n_elem)
         k_copies, v_copies = expand == 1, expand in (1, 2)
         kern_expand = 1 if (k_copies and v_copies) else (2 if v_copies else 0)          # what the forward pass materialises
         q = torch.empty((B, G * qpk, T, hs), dtype=qkv.dtype, device=qkv.device)

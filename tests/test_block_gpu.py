@@ -379,3 +379,30 @@ def test_rope_split_group_views_are_views():
     assert k3.untyped_storage().nbytes() == B * G * T * hs * 2          # one copy per key head, not per query head
     _, k4, v4 = ops.RopeQKVSplit.apply(qkv, cos, sin, hs, 4)
     assert k4.shape == (B, G, T, hs) and v4.stride(1) == 0
+
+
+def test_flat_grad_bucket_with_bf16_parameters_on_device():
+    """bf16 LoRA parameters with the fp32 bucket (the "bf16-true" fine-tune): gradients are copied into the bucket's fp32 views
+    at the boundary, accumulate there across micro-batches, and come back in the parameter's dtype; fp32 parameters alias it."""
+    from fastmax_experiments_amd import dp
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(8, 64, device="cuda").to(torch.bfloat16))
+    b = torch.nn.Parameter(torch.randn(64, 8, device="cuda"))
+    bucket = dp.FlatGradBucket([a, b], dtype=torch.float32)
+    assert b.grad is not None and b.grad.data_ptr() == bucket._views[1].data_ptr() and a.grad is None
+    x = torch.randn(16, 64, device="cuda")
+    want_a = torch.zeros(8, 64, device="cuda")
+    want_b = torch.zeros(64, 8, device="cuda")
+    for _ in range(3):                                               # three micro-batches, gathered after each
+        y = (x.to(torch.bfloat16) @ a.t()).float() @ b.t()
+        y.square().mean().backward()
+        want_a += a.grad.float()
+        bucket.gather()
+        assert a.grad is None
+    want_b = b.grad.clone()
+    bucket.all_reduce_mean()                                          # one rank: no collective, gradients handed back
+    assert a.grad.dtype == torch.bfloat16 and a.grad.is_cuda
+    assert torch.allclose(a.grad.float(), want_a, rtol=1e-2, atol=1e-3)
+    assert torch.equal(b.grad, want_b) and b.grad.data_ptr() == bucket._views[1].data_ptr()
+    bucket.zero()
+    assert a.grad is None and float(bucket.flat.abs().sum()) == 0.0 and b.grad.data_ptr() == bucket._views[1].data_ptr()

@@ -192,3 +192,24 @@ def test_on_chip_head_loss_rows_exact():
     # argument checks: a contraction length that is not a whole number of 64-column steps
     assert L.fastmax_hip_lmhead_ce_forward(x.data_ptr(), K, w.data_ptr(), t.data_ptr(), loss.data_ptr(), lse.data_ptr(),
                                            ws.data_ptr(), None, 0, M, V, 100, -1, None) != 0
+
+
+def test_kept_logits_are_consumed_once():
+    """the default fine-tune route keeps the bf16 logits and turns them into d(logits) in place: same loss and gradient as
+    the recompute route, and a second backward pass through the same graph is refused instead of using the overwritten buffer"""
+    from fastmax_experiments_amd.loss import _LMHeadLoss
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(300, 128, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(1000, 128, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    t = torch.randint(0, 1000, (300,), generator=g).cuda()
+    res = []
+    for keep in (False, True):
+        xa = x.clone().requires_grad_(True)
+        loss = _LMHeadLoss.apply(xa, w, t, -1, 128, keep)
+        loss.backward(retain_graph=True)
+        res.append((float(loss), xa.grad.float().clone()))
+        if keep:
+            with pytest.raises(RuntimeError):
+                loss.backward()
+    assert res[0][0] == res[1][0]
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-2 * float(res[0][1].abs().max())

@@ -24,6 +24,9 @@ cases = [
     ("p=1 linear scan", "fastmax", "auto", (1, 4, 4096, 64), "bf16", 1, True),
     ("p=1 linear scan", "fastmax", "auto", (1, 4, 4096, 64), "f16", 1, True),
     ("p=1 linear scan, D=128 (8 waves)", "fastmax", "auto", (1, 4, 4096, 128), "bf16", 1, True),
+    ("p=1 D=128 fp32: two-part forward, role-swapped scan backward (round 2)", "fastmax", "auto", (1, 2, 4096, 128), "f32", 1, True),
+    ("p=1 D=128 fp16: same", "fastmax", "auto", (1, 2, 4096, 128), "f16", 1, True),
+    ("p=1 D=96 fp32: same, padded", "fastmax", "auto", (1, 2, 2048, 96), "f32", 1, True),
     ("p=1 linear scan, padded head size", "fastmax", "auto", (1, 4, 2048, 48), "f32", 1, True),
     ("p=1 sequence split (4 heads x 16k)", "fastmax", "auto", (1, 4, 16384, 64), "f32", 1, True),
     ("linearmax (fused prologue fwd, HIP prologue bwd)", "linearmax", "auto", (1, 4, 4096, 64), "bf16", 1, True),

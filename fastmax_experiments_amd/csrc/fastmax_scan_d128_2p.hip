@@ -25,7 +25,13 @@ struct ScanParams {
     const float *wbuf, *ebuf;       // w_i = 1/g_i, e_i = -w_i c_i   (B,H,N)
     int H, N, D, dtype;
     float beta, out_scale;
+    // sequence split (few heads): workgroup = (head, segment of `cps` chunks).  A first launch (STATE_ONLY) leaves every
+    // segment's own sums in `state`; the main launch starts segment s from the sum of the records before it (after it, for
+    // the reverse scans).  Record: S2 as the accumulators hold it ([mt][wave][lane] x 4 floats) + S1 (128 floats).
+    float* state;
+    int nseg, cps;
 };
+constexpr int kScanRec = 8 * 8 * 64 * 4 + 128;       // floats per (head, segment) record
 
 // w, e of every row: one wave per row.  grid = (ceil(N/4), B*H), block = 256
 template <typename TIN>
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void scan_prep_kernel(const void* go, Strides3
     }
 }
 
-template <typename TIN, int MODE>
+template <typename TIN, int MODE, bool STATE_ONLY = false>
 __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
     constexpr int NP = 2, EPL = InTraits<TIN>::EPL;
     static_assert(InTraits<TIN>::NP == 2, "two-part operands");
@@ -69,8 +75,11 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qt = w & 3, dh = w >> 2;
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.x, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.x / prm.nseg, seg = blockIdx.x - bh * prm.nseg, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
+    if constexpr (STATE_ONLY) {
+        if (seg == (REV ? 0 : prm.nseg - 1)) return;                 // nobody starts from this segment's sums
+    }
     const TIN* xb = reinterpret_cast<const TIN*>(prm.x) + (int64_t)b * prm.xs.sb + (int64_t)h * prm.xs.sh;
     const TIN* yb = reinterpret_cast<const TIN*>(prm.y) + (int64_t)b * prm.ys.sb + (int64_t)h * prm.ys.sh;
     const TIN* zb = reinterpret_cast<const TIN*>(prm.z) + (int64_t)b * prm.zs.sb + (int64_t)h * prm.zs.sh;
@@ -87,10 +96,12 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
         yload.load(c, ry);
         zload.load(c, rz);
         const int row = c * C + 16 * qt + r;                       // this wave's output row on this lane
+        if constexpr (!STATE_ONLY) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int u = 0; u < QL; ++u) rx[ks][u] = load_piece<TIN, true>(xb, prm.xs.sn, row, N, (32 * ks + 8 * q4) / EPL + u, D);
+                for (int u = 0; u < QL; ++u) rx[ks][u] = load_piece<TIN, true>(xb, prm.xs.sn, row, N, (32 * ks + 8 * q4) / EPL + u, D);
+        }
         if constexpr (YSCALE || ZSCALE) {
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
                 rws[ps] = sr < N ? wb[sr] : 0.f;
             }
         }
-        if constexpr (MODE == SCAN_DQ) {
+        if constexpr (MODE == SCAN_DQ && !STATE_ONLY) {
             rwx = row < N ? wb[row] : 0.f;
             rex = row < N ? eb[row] : 0.f;
         }
@@ -125,16 +136,33 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
         }
         if (q4 == 0) reinterpret_cast<float*>(smem + S1V)[16 * w + r] = s1acc[0];
     };
-    for (int i = tid; i < (2 * SIMG) / 16; i += 512) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
-    if (tid < DP) reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
     s1acc = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) s2acc[mt] = f32x4{0, 0, 0, 0};
-    const int c_first = REV ? nchunks - 1 : 0, c_step = REV ? -1 : 1;
+    const int c_lo = seg * prm.cps, c_hi = min(nchunks, c_lo + prm.cps), nloc = c_hi - c_lo;
+    const int c_first = REV ? c_hi - 1 : c_lo, c_step = REV ? -1 : 1;
+    bool has_prefix = false;
+    if constexpr (!STATE_ONLY) {
+        // the sums of the segments this one continues: earlier ones (forward scan) or later ones (reverse scans)
+        const int s_lo = REV ? seg + 1 : 0, s_hi = REV ? prm.nseg : seg;
+        has_prefix = s_hi > s_lo;
+        for (int sg = s_lo; sg < s_hi; ++sg) {
+            const float* rec = prm.state + ((int64_t)bh * prm.nseg + sg) * kScanRec;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) s2acc[mt] += *reinterpret_cast<const f32x4*>(rec + ((mt * 8 + w) * 64 + lane) * 4);
+            if (q4 == 0) s1acc[0] += rec[8 * 8 * 64 * 4 + 16 * w + r];
+        }
+    }
+    if (has_prefix) {
+        publish();
+    } else {
+        for (int i = tid; i < (2 * SIMG) / 16; i += 512) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
+        if (tid < DP) reinterpret_cast<float*>(smem + S1V)[tid] = 0.f;
+    }
     issue(c_first);
     __syncthreads();
 
-    for (int it = 0, c = c_first; it < nchunks; ++it, c += c_step) {
+    for (int it = 0, c = c_first; it < nloc; ++it, c += c_step) {
         const int n0 = c * C;
         // ---- staging: y and z rows (one of them scaled by w of its row) as hi / lo images; x fragments in registers -------
 #pragma unroll
@@ -164,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
         }
         Frag<NP> xf[KS];
         const float alpha_r = MODE == SCAN_DQ ? rex : 1.0f;          // alpha of this lane's output row (DQ), else unused / 1
-        {
+        if constexpr (!STATE_ONLY) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float xq[8];
@@ -188,8 +216,9 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
                 xf[ks].p[1] = cat4(l0, l1);
             }
         }
-        if (it + 1 < nchunks) issue(c + c_step);
+        if (it + 1 < nloc) issue(c + c_step);
         __syncthreads();                                             // B1
+        if constexpr (!STATE_ONLY) {
         // ---- phase A: output rows of tile qt, output columns of d-half dh ---------------------------------------------
         f32x4 oacc[4];
 #pragma unroll
@@ -260,6 +289,7 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
                 if (col < D) store4_any(prm.out, prm.dtype, ((int64_t)bh * N + gi) * D + col, oacc[t] * prm.out_scale);
             }
         }
+        }   // !STATE_ONLY
         // ---- phase B: S2[:, 16w ..] += Y^T Z;  S1 += sum_c alpha_c z_c  (ones, or the chunk's e, times Z) --------------
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -290,16 +320,24 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
             }
         }
         __syncthreads();                                             // B2
-        if (it + 1 < nchunks) publish();
+        if constexpr (!STATE_ONLY) {
+            if (it + 1 < nloc) publish();
+        }
+    }
+    if constexpr (STATE_ONLY) {
+        float* rec = prm.state + ((int64_t)bh * prm.nseg + seg) * kScanRec;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(rec + ((mt * 8 + w) * 64 + lane) * 4) = s2acc[mt];
+        if (q4 == 0) rec[8 * 8 * 64 * 4 + 16 * w + r] = s1acc[0];
     }
 }
 
-template <typename TIN, int MODE>
-static int launch_scan_t(const ScanParams& prm, int nb, hipStream_t stream) {
+template <typename TIN, int MODE, bool STATE_ONLY>
+static int launch_scan_k(const ScanParams& prm, int nb, hipStream_t stream) {
     constexpr int DP = 128;
     constexpr int lds = 4 * 64 * DP * 2 + 2 * DP * DP * 2 + DP * 4 + 256;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_d128_2p_kernel<TIN, MODE>;
+    auto kern = scan_d128_2p_kernel<TIN, MODE, STATE_ONLY>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -310,6 +348,27 @@ static int launch_scan_t(const ScanParams& prm, int nb, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// one scan: with a sequence split, the segments' own sums first
+template <typename TIN, int MODE>
+static int launch_scan_t(const ScanParams& prm, int nb, hipStream_t stream) {
+    if (prm.nseg > 1) {
+        const int rc = launch_scan_k<TIN, MODE, true>(prm, nb * prm.nseg, stream);
+        if (rc) return rc;
+    }
+    return launch_scan_k<TIN, MODE, false>(prm, nb * prm.nseg, stream);
+}
+
+// few heads: segments of at least 8 chunks (512 tokens) until ~256 workgroups exist (one per CU: 132 KB of LDS each)
+static void scan_split_plan(const fastmax_problem& p, int& nseg, int& cps) {
+    const int nchunks = (p.Nq + 63) / 64, BH = p.B * p.H;
+    static const int target = [] { const char* e = getenv("FASTMAX_SCAN_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+    int want = target / (BH > 0 ? BH : 1);
+    if (want > nchunks / 8) want = nchunks / 8;
+    if (want < 1) want = 1;
+    cps = (nchunks + want - 1) / want;
+    nseg = (nchunks + cps - 1) / cps;
+}
+
 bool scan_bwd_supported(const fastmax_problem& p) {
     // the shapes fastmax_mfma_d128_2p.hip serves forwards: two-part operands at 64 < D <= 128
     if (!(p.p == 1 && p.causal) || p.D <= 64 || p.D > 128 || p.in_dtype != p.out_dtype || p.Nq < 512) return false;
@@ -317,7 +376,11 @@ bool scan_bwd_supported(const fastmax_problem& p) {
     if (p.in_dtype == FASTMAX_F16) return (p.D % 8) == 0;
     return false;
 }
-size_t scan_bwd_workspace(const fastmax_problem& p) { return 2 * sizeof(float) * (size_t)p.B * p.H * p.Nq + 32; }
+size_t scan_bwd_workspace(const fastmax_problem& p) {
+    int nseg, cps;
+    scan_split_plan(p, nseg, cps);
+    return 2 * sizeof(float) * (size_t)p.B * p.H * p.Nq + 64 + (nseg > 1 ? sizeof(float) * (size_t)p.B * p.H * nseg * kScanRec : 0);
+}
 
 template <typename TIN>
 static int launch_scan_bwd_t(const BwdArgs& a) {
@@ -325,20 +388,23 @@ static int launch_scan_bwd_t(const BwdArgs& a) {
     const int BH = p.B * p.H;
     float* wbuf = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(a.workspace) + 15) & ~(uintptr_t)15);
     float* ebuf = wbuf + (size_t)BH * p.Nq;
+    float* state = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ebuf + (size_t)BH * p.Nq) + 15) & ~(uintptr_t)15);
+    int nseg, cps;
+    scan_split_plan(p, nseg, cps);
     hipLaunchKernelGGL((scan_prep_kernel<TIN>), dim3((p.Nq + 3) / 4, BH), dim3(256), 0, a.stream, a.grad_o, a.gos, a.o, a.g, wbuf, ebuf,
                        p.H, p.Nq, p.D);
     const Strides3 os{(int64_t)p.H * p.Nq * p.D, (int64_t)p.Nq * p.D, (int64_t)p.D};
     (void)os;
     // dQ: x = grad_o (scaled by w), y = v, z = k
-    ScanParams dq{a.grad_o, a.v, a.k, a.gos, a.vs, a.ks, a.dq, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, 1.0f, p.a};
+    ScanParams dq{a.grad_o, a.v, a.k, a.gos, a.vs, a.ks, a.dq, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, 1.0f, p.a, state, nseg, cps};
     int rc = launch_scan_t<TIN, SCAN_DQ>(dq, BH, a.stream);
     if (rc) return rc;
     // dV: x = k, y = q, z = grad_o (scaled by w)
-    ScanParams dv{a.k, a.q, a.grad_o, a.ks, a.qs, a.gos, a.dv, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, p.a, 1.0f};
+    ScanParams dv{a.k, a.q, a.grad_o, a.ks, a.qs, a.gos, a.dv, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, p.a, 1.0f, state, nseg, cps};
     rc = launch_scan_t<TIN, SCAN_DV>(dv, BH, a.stream);
     if (rc) return rc;
     // dK: x = v, y = grad_o (scaled by w), z = q
-    ScanParams dk{a.v, a.grad_o, a.q, a.vs, a.gos, a.qs, a.dk, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, 1.0f, p.a};
+    ScanParams dk{a.v, a.grad_o, a.q, a.vs, a.gos, a.qs, a.dk, wbuf, ebuf, p.H, p.Nq, p.D, p.in_dtype, 1.0f, p.a, state, nseg, cps};
     return launch_scan_t<TIN, SCAN_DK>(dk, BH, a.stream);
 }
 

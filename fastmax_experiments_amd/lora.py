@@ -134,6 +134,18 @@ class NF4Scales:
         return self.tensors[0].device
 
 
+def scales_of(base) -> "NF4Scales":
+    """the NF4Scales of an NF4Linear, rebuilt only when its quant_state tensors changed (a double-quantised state holds its
+    offset as a device scalar: reading it costs a host synchronisation, which must not happen once per forward call)"""
+    qs = base.weight.quant_state
+    key = (qs[0].data_ptr(), None if qs[4] is None else (qs[4][1][0].data_ptr(), qs[4][1][1].data_ptr()))
+    hit = base.__dict__.get("_scales_cache")
+    if hit is None or hit[0] != key:
+        hit = (key, NF4Scales(qs))
+        base.__dict__["_scales_cache"] = hit
+    return hit[1]
+
+
 def block_scales(quant_state) -> torch.Tensor:
     """fp32 absmax vector of a quant_state, whichever way it is stored (host / device tensor ops)."""
     if quant_state[4] is None:
@@ -222,6 +234,7 @@ class NF4Linear(nn.Module):
         out._buffers = {k: copy.deepcopy(v, memo) for k, v in self._buffers.items()}
         out._modules = {}
         out._dense_cache = None                                 # never share the decoded copy of the original
+        out.__dict__.pop("_scales_cache", None)
         return out
 
     def dequantize(self, dtype=torch.float32) -> torch.Tensor:
@@ -588,7 +601,7 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    scales = NF4Scales(base.weight.quant_state)
+    scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
         y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused")
     else:
@@ -624,7 +637,7 @@ def qlora_linear(x, base: NF4Linear, ea, eb):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, NF4Scales(base.weight.quant_state), bias, N, K, base._dense_cache)
+    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, scales_of(base), bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N).to(x.dtype)
 
 

@@ -115,8 +115,9 @@ def _kept_backward(ctx, grad_out):
         raise RuntimeError("second backward pass through lm_head_cross_entropy: the kept logits were turned into d(logits) in "
                            "place by the first one (FASTMAX_HEAD_KEEP_BYTES=0 recomputes them instead)")
     x2d, weight, targets1d, lse, n, logits = ctx.saved_tensors
-    scale = float(grad_out.float() / n)                                     # one host sync per backward (scalar loss)
-    _rows_backward(logits, targets1d, lse, None, scale, ctx.ignore_index, logits)
+    # d(loss)/d(row loss) stays on the device (a per-row vector for the kernel): no host synchronisation in the step
+    row_grad = (grad_out.float() / n).reshape(1).expand(logits.shape[0]).contiguous()
+    _rows_backward(logits, targets1d, lse, row_grad, 1.0, ctx.ignore_index, logits)
     ctx.logits_consumed = True
     dx = logits @ weight if ctx.needs_input_grad[0] else None
     dw = (logits.t() @ x2d) if ctx.needs_input_grad[1] else None
@@ -154,14 +155,14 @@ class _LMHeadLoss(torch.autograd.Function):
             return _kept_backward(ctx, grad_out)
         x2d, weight, targets1d, lse, n = ctx.saved_tensors
         M = x2d.shape[0]
-        scale = float(grad_out.float() / n)                                 # one host sync per backward (scalar loss)
+        row_grad = (grad_out.float() / n).reshape(1).expand(M).contiguous()  # stays on the device: no host synchronisation
         dx = torch.empty_like(x2d) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(weight, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         for r0 in range(0, M, ctx.chunk_rows):
             xs = x2d[r0:r0 + ctx.chunk_rows]
             logits = xs @ weight.t()
-            _rows_backward(logits, targets1d[r0:r0 + ctx.chunk_rows], lse[r0:r0 + ctx.chunk_rows], None, scale, ctx.ignore_index,
-                           logits)                                           # in place: logits become d(logits)
+            _rows_backward(logits, targets1d[r0:r0 + ctx.chunk_rows], lse[r0:r0 + ctx.chunk_rows], row_grad[r0:r0 + ctx.chunk_rows],
+                           1.0, ctx.ignore_index, logits)                    # in place: logits become d(logits)
             if dx is not None:
                 dx[r0:r0 + ctx.chunk_rows] = logits @ weight
             if dw is not None:

@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--micro-batch", type=int, default=2)
     ap.add_argument("--accum", type=int, default=2, help="dp_step: gradient accumulation iterations per optimizer step and rank")
     ap.add_argument("--toy", action="store_true", help="dp_step: CPU stand-in model (rehearsal of the multi-rank control flow)")
+    ap.add_argument("--graph", action="store_true", help="dp_step: replay each micro-batch (forward + backward) as one captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -125,7 +126,8 @@ def dp_step_main(args, dev, rank, world, multi, json_fd):
     from fastmax_experiments_amd import finetune_step
     seq = args.seq if args.seq != 4096 or args.config == "Llama-2-7b-hf" else 2048       # config 3 default: seq 2048
     res = finetune_step.run(args.config, args.layers, args.attn, seq, args.micro_batch, args.accum, args.steps, args.warmup,
-                            dev, rank=rank, world=world, toy=args.toy, precondition_ms=0.0 if args.toy else args.precondition_ms)
+                            dev, rank=rank, world=world, toy=args.toy, precondition_ms=0.0 if args.toy else args.precondition_ms,
+                            graph=args.graph)
     if rank == 0:
         line = {
             "metric": "data-parallel QLoRA fine-tune step, tokens/sec (whole job)", "workload": "dp_step",
@@ -141,7 +143,7 @@ def dp_step_main(args, dev, rank, world, multi, json_fd):
             "allreduce": {"ms": round(res["allreduce_ms"], 4), "bucket_bytes": res["bucket_bytes"],
                           "per_step": 1, "backend": dist.get_backend() if multi else "none (one rank)"},
             "trainable_params": res["trainable_params"], "last_loss": round(res["last_loss"], 5),
-            "precondition_ms": 0.0 if args.toy else args.precondition_ms,
+            "precondition_ms": 0.0 if args.toy else args.precondition_ms, "hip_graph": bool(args.graph and not args.toy),
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi:

@@ -146,13 +146,44 @@ class DataParallelStepper:
         """milliseconds of every timed all-reduce so far (synchronises the device events)"""
         return [t if isinstance(t, float) else t[0].elapsed_time(t[1]) for t in self.comm_ms]
 
+    def capture(self, sample_batch) -> None:
+        """Record one micro-batch (forward + backward of loss / accum into the bucket) as a HIP graph; `micro_step` then
+        copies its batch into the recorded input tensors and replays.  The step is ~600 kernel launches of 5-500 us each:
+        replayed as one graph the GPU no longer waits for the host between them.  The collective and the optimizer stay
+        outside the graph.  Needs static shapes (every micro-batch like `sample_batch`) and a step without host
+        synchronisation -- which the HIP path is (workspaces come from the caching allocator, scalars stay on the device)."""
+        dev = self.bucket.flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("graph capture needs a HIP device")
+        self._static = tuple(t.clone() for t in sample_batch)
+        saved = self.bucket.flat.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up on a side stream: lazy initialisations, allocator pools
+            for _ in range(2):
+                (self.loss_fn(self.model, self._static) / self.accum).backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self.loss_fn(self.model, self._static)
+            (self._static_loss / self.accum).backward()
+        self.bucket.flat.copy_(saved)                      # warm-up and capture accumulated into the bucket: undo
+
+    _graph = None
+
     def micro_step(self, batch) -> torch.Tensor:
         """One micro-batch: forward, backward of loss/accum; at the boundary all-reduce + optimizer step.
         Returns the (unscaled) micro-batch loss."""
         self.iter_num += 1
         is_accumulating = self.iter_num % self.accum != 0
-        loss = self.loss_fn(self.model, batch)
-        (loss / self.accum).backward()
+        if self._graph is not None:
+            for dst, src in zip(self._static, batch):
+                dst.copy_(src)
+            self._graph.replay()
+            loss = self._static_loss
+        else:
+            loss = self.loss_fn(self.model, batch)
+            (loss / self.accum).backward()
         if not is_accumulating:
             self._timed_all_reduce()
             if self.train.max_norm is not None:

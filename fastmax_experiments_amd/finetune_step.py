@@ -73,7 +73,7 @@ class ToyLoRA(nn.Module):
 
 
 def run(config: str, n_layer: int, attn_alg: str, seq: int, micro_batch: int, accum: int, steps: int, warmup: int, device,
-        rank: int = 0, world: int = 1, toy: bool = False, precondition_ms: float = 0.0) -> dict:
+        rank: int = 0, world: int = 1, toy: bool = False, precondition_ms: float = 0.0, graph: bool = False) -> dict:
     """`warmup` untimed + `steps` timed optimizer steps; -> timings (seconds / milliseconds, this rank)."""
     on_gpu = device.type == "cuda"
     multi = dist.is_available() and dist.is_initialized() and world > 1
@@ -94,6 +94,8 @@ def run(config: str, n_layer: int, attn_alg: str, seq: int, micro_batch: int, ac
     train = dp.TrainArgs(global_batch_size=micro_batch * accum * world, micro_batch_size=micro_batch)
     st = dp.DataParallelStepper(model, opt, train, lambda m, b: m.loss(b[0], b[1], cos, sin), time_comm=True)
     assert st.accum == accum
+    if graph and on_gpu and not toy:
+        st.capture((x[0], tgt[0]))
 
     def sync():
         if on_gpu:

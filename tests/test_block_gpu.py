@@ -406,3 +406,34 @@ def test_flat_grad_bucket_with_bf16_parameters_on_device():
     assert torch.equal(b.grad, want_b) and b.grad.data_ptr() == bucket._views[1].data_ptr()
     bucket.zero()
     assert a.grad is None and float(bucket.flat.abs().sum()) == 0.0 and b.grad.data_ptr() == bucket._views[1].data_ptr()
+
+
+def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
+    """`DataParallelStepper.capture`: one micro-batch (QLoRA attention stack + lm-head loss, forward + backward into the flat
+    bucket) recorded as a HIP graph and replayed with new batches -- same losses and the same parameters after the optimizer
+    steps as the eager step (the kernels are deterministic: bitwise equality)."""
+    from fastmax_experiments_amd import dp, finetune_step
+    from fastmax_experiments_amd.attention_block import build_rope_cache
+    dev = torch.device("cuda")
+    T, mb, accum = 256, 2, 2
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(2 * accum, mb, T, 128, device=dev, generator=g).to(torch.bfloat16)
+    tgt = torch.randint(0, 512, (2 * accum, mb, T), device=dev, generator=g)
+    finals, losses = [], []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = finetune_step.AttentionStack("pythia-14m", 2, "fastmax", vocab=512).prepare(dev)
+        cos, sin = (t.to(torch.bfloat16) for t in build_rope_cache(T, model.rope_n_elem, device=dev))
+        params = dp.trainable_lora_parameters(model)
+        opt = torch.optim.AdamW(params, lr=1e-3)
+        st = dp.DataParallelStepper(model, opt, dp.TrainArgs(global_batch_size=mb * accum, micro_batch_size=mb),
+                                    lambda m, b: m.loss(b[0], b[1], cos, sin))
+        if graph:
+            st.capture((x[0], tgt[0]))
+            assert float(st.bucket.flat.abs().sum()) == 0.0          # warm-up and capture left nothing in the bucket
+        ls = [float(st.micro_step((x[i], tgt[i]))) for i in range(2 * accum)]
+        assert st.step_count == 2
+        losses.append(ls)
+        finals.append(torch.cat([p.detach().float().reshape(-1) for p in params]).clone())
+    assert losses[0] == losses[1]
+    assert torch.equal(finals[0], finals[1])

@@ -56,7 +56,7 @@ struct GemmParams {
     const float* lse;         // EPI 2: [M] log sum exp of the row
     float gscale;             // EPI 2: d(loss)/d(row loss)
     int64_t ignore_index;
-    unsigned long long* stamps;   // diagnostics: [workgroup][2] = (shader cycles, 100 MHz ticks) of the main loop; null normally
+    unsigned long long* stamps;   // diagnostics: [workgroup][4] = main loop (shader cycles, 100 MHz ticks), wave 0's wait for its copies, for the barrier; null normally
 };
 
 __constant__ float kGemmNF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
@@ -85,7 +85,7 @@ constexpr int LDS_BYTES = LUT + 64;                                          // 
 //   2 (loss backward): dz = (exp(z - lse_m) - [n == t_m]) * gscale (0 for rows that are not scored) stored as bf16
 //   3 (loss forward that keeps the logits for the backward pass): 1, then the tile stored as bf16 like 0
 // so the (tokens x vocabulary) logits are never written or read (lit_gpt/utils.py:228-272 after lora.py:547-550).
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false>
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false, bool STAG = false>
 __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     };
 
     const int KT = K / BK;
-    unsigned long long t0c = 0, t0r = 0;
+    unsigned long long t0c = 0, t0r = 0, wait_dma = 0, wait_bar = 0;
     if (prm.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
     // prologue: tile 0 -> stage 0; the codes of tile 1 wait in registers
     dma_tile(prm.x, prm.ldx, m0, M, 0, smem);
@@ -306,6 +306,45 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             half(a1, a0, nf, nf + XT, 0, true);
         }
         __syncthreads();
+    } else if constexpr (STAG) {
+        // the two waves of a SIMD (w, w + 4) leave the barrier together; with the same program both would issue copies, then
+        // read fragments, then multiply -- and the matrix pipe idles while both are in their loading part (stamps: 1200 of
+        // 3300 cycles per step).  Here waves 0-3 issue their copies of tile kt+1 first, waves 4-7 after their first 32-deep
+        // half: one of the pair is always multiplying.
+        const bool late = w >= 4;
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+            const bool more = kt + 1 < KT;
+            if (more && !late) {
+                dma_tile(prm.x, prm.ldx, m0, M, (kt + 1) * BK, nxt);
+                if constexpr (!WNF4) dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 1) * BK, nxt + XT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_k32(cur, cur + XT, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && late) {
+                dma_tile(prm.x, prm.ldx, m0, M, (kt + 1) * BK, nxt);
+                if constexpr (!WNF4) dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 1) * BK, nxt + XT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_k32(cur, cur + XT, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WNF4) {
+                if (more) decode_codes(nxt + XT);
+                if (kt + 2 < KT) load_codes((kt + 2) * BK);
+            }
+            if (prm.stamps) {
+                const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long tb = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();
+                wait_dma += tb - ta;
+                wait_bar += __builtin_amdgcn_s_memtime() - tb;
+            } else {
+                __syncthreads();
+            }
+        }
     } else if constexpr (REG) {
         for (int kt = 0; kt < KT; ++kt) {
             char* cur = smem + (kt & 1) * STAGE;
@@ -387,6 +426,15 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+        } else if (prm.stamps) {
+            // diagnostics: how long this wave waits for its own copies of tile kt+1, and then for the other waves
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long tc = __builtin_amdgcn_s_memtime();
+            wait_dma += tb - ta;
+            wait_bar += tc - tb;
         } else {
             __syncthreads();                                         // tile kt+1 landed (DMA drained by the barrier's wait), tile kt consumed
         }
@@ -396,8 +444,10 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
         asm volatile("" ::"v"(pf_sink));
     }
     if (prm.stamps && tid == 0) {
-        prm.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-        prm.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        prm.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        prm.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        prm.stamps[4 * blockIdx.x + 2] = wait_dma;
+        prm.stamps[4 * blockIdx.x + 3] = wait_bar;
     }
     // ---- LoRA branch: one more step over the padded rank ------------------------------------------------------------------
     if (prm.ea && prm.eb) {
@@ -565,9 +615,9 @@ __global__ __launch_bounds__(256) void lmhead_ce_combine_kernel(const float* par
     loss[m] = (t != ignore_index && t >= 0 && t < V) ? l - ztgt[m] : 0.f;
 }
 
-template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false>
+template <bool WNF4, bool HALVES, bool PF = false, bool ILV = false, int EPI = 0, bool REG = false, bool PIPE = false, bool SPEC = false, bool STAG = false>
 static int launch_gemm256(GemmParams p, hipStream_t stream) {
-    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV, EPI, REG, PIPE, SPEC>;
+    auto kern = qlora_gemm256_kernel<WNF4, HALVES, PF, ILV, EPI, REG, PIPE, SPEC, STAG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
@@ -589,7 +639,7 @@ static unsigned long long* g_gemm_stamps = nullptr;
 
 extern "C" {
 
-// diagnostics (tools/gemm_clock.py): a device buffer of 2 x (number of workgroups) 64-bit words that the next
+// diagnostics (tools/gemm_clock.py): a device buffer of 4 x (number of workgroups) 64-bit words that the next
 // fastmax_hip_qlora_gemm launches fill with the main loop's shader cycles and 100 MHz ticks per workgroup; null turns it off
 void fastmax_hip_debug_gemm_stamps(void* buffer) { g_gemm_stamps = reinterpret_cast<unsigned long long*>(buffer); }
 
@@ -618,6 +668,8 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
     const int sched = tune_get(TUNE_GEMM_SCHED);
+    if (sched == 11) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, false, true>(p, st)
+                                     : launch_gemm256<false, false, false, false, 0, false, false, false, true>(p, st);
     if (sched == 9) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, true>(p, st)
                                     : launch_gemm256<false, false, false, false, 0, false, false, true>(p, st);
     if (sched == 10) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, true, true>(p, st)

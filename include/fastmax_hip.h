@@ -293,8 +293,8 @@ int fastmax_hip_lmhead_ce_backward(const void* x, int64_t ldx, const void* w, co
                                    float grad_scale, void* dz, int64_t ldz, int M, int V, int K, int64_t ignore_index,
                                    void* stream);
 
-/*      diagnostics: a device buffer of 2 x (workgroups) 64-bit words that later fastmax_hip_qlora_gemm launches fill with the
- *      main loop's (shader cycles, 100 MHz ticks) per workgroup; null turns it off (tools/gemm_clock.py)                   */
+/*      diagnostics: a device buffer of 4 x (workgroups) 64-bit words that later fastmax_hip_qlora_gemm launches fill with the
+ *      main loop's (shader cycles, 100 MHz ticks, cycles waiting for its copies, cycles waiting at the barrier) per workgroup; null turns it off (tools/gemm_clock.py)                   */
 void fastmax_hip_debug_gemm_stamps(void* buffer);
 
 /* ---- QLoRA linear at training sizes: the rank-r products around the library GEMM of the frozen weight

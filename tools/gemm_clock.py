@@ -20,8 +20,8 @@ def main():
     L.fastmax_hip_debug_gemm_stamps.argtypes = [ctypes.c_void_p]
     L.fastmax_hip_debug_gemm_stamps.restype = None
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
-    stamps = torch.zeros(nwg, 2, dtype=torch.int64, device="cuda")
-    for sched in (0, 8, 9, 10):
+    stamps = torch.zeros(nwg, 4, dtype=torch.int64, device="cuda")
+    for sched in (0, 9, 11):
         L.fastmax_hip_tune(b"gemm_sched", sched)
         t_end = time.perf_counter() + 1.0
         n = 0
@@ -39,8 +39,9 @@ def main():
         L.fastmax_hip_debug_gemm_stamps(None)
         cyc = stamps[:, 0].double().median().item()
         ticks = stamps[:, 1].double().median().item()
+        wd, wb = stamps[:, 2].double().median().item() / (K // 64), stamps[:, 3].double().median().item() / (K // 64)
         print(f"sched {sched}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.0f} TF/s; main loop {cyc:.0f} cycles = {cyc / (K // 64):.0f} per K step "
-              f"(matrix pipe: 2048); in-kernel clock {cyc / ticks * 0.1:.2f} GHz", flush=True)
+              f"(matrix pipe: 2048), of which wave 0 waits {wd:.0f} for its copies + {wb:.0f} at the barrier; in-kernel clock {cyc / ticks * 0.1:.2f} GHz", flush=True)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from attention_mechanisms.fastmax import fastmax
+from attention_mechanisms.fastmax_hack import fastmax_hack
 from oracle import fastmax_oracle as orc
 
 DT = {"f32": (torch.float32, 2e-4), "bf16": (torch.bfloat16, 3e-2), "f16": (torch.float16, 4e-3)}
@@ -71,6 +72,22 @@ def main():
                 qd_in, kd, vd = qd, kd0.repeat_interleave(rep_, dim=1), vd0.repeat_interleave(rep_, dim=1)
         else:
             qd_in, kd, vd, kf, vf = qd, kd0, vd0, k, v
+        if gk == H and rng.random() < 0.2 and Nq >= 2:
+            # linearmax (fastmax_hack.py:5-60), forward: prologue + operator against the oracle's restatement
+            desc = f"case {ci}: linearmax {dt} p={p} mask={mask} (B,H,Nq,Nk,D)=({B},{H},{Nq},{Nk},{D}) layouts={kinds}"
+            try:
+                with torch.no_grad():
+                    o = fastmax_hack(qd, kd, vd, p=p, mask=mask)
+            except Exception as e:                        # noqa: BLE001
+                print("RAISED", desc, type(e).__name__, str(e)[:200], flush=True)
+                bad += 1
+                continue
+            ro = np.asarray(orc.linearmax_fwd(q.double().numpy(), k.double().numpy(), v.double().numpy(), p=p, mask=mask))
+            e_o = nw(o.double().cpu().numpy(), ro)
+            ok = e_o <= tol
+            bad += 0 if ok else 1
+            print("ok  " if ok else "BAD ", desc, f"o={e_o:.2e}", flush=True)
+            continue
         desc = f"case {ci}: {dt} p={p} mask={mask} (B,H,Nq,Nk,D)=({B},{H},{Nq},{Nk},{D}) groups={gk} views={views} layouts={kinds}"
         try:
             o = fastmax(qd_in, kd, vd, mask=mask, p=p).reshape(B, H, Nq, D)

@@ -568,6 +568,129 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     }
 }
 
+// The same product for row counts whose 256 x 256 tiles would leave CUs idle (M = 2048 .. 8192 at the layer widths of the
+// fine-tune configs: 64 .. 160 tiles on 256 CUs): 128 x 256 output tiles, dense bf16 weight (the decode-once route), the same
+// images, loop and epilogue.  Eight waves as 2 (m) x 4 (n): a wave owns 64 x 64 (16 accumulator tiles); per K step a wave
+// issues 2 + 4 LDS-DMA pieces and 32 MFMAs.  Two stages of 16 KB (x) + 32 KB (W) = 96 KB.
+namespace g128 {
+constexpr int BM = 128, BN = 256, BK = 64;
+constexpr int XT = BM * BK * 2, WT = BN * BK * 2, STAGE = XT + WT;
+constexpr int LDS_BYTES = 2 * STAGE;                                         // 98304
+}  // namespace g128
+
+__global__ __launch_bounds__(512, 1) void qlora_gemm128_kernel(GemmParams prm) {
+    using namespace g128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int r = lane & 15, q4 = lane >> 4;
+    const int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int M = prm.M, N = prm.N, K = prm.K;
+    const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ drow;
+    // piece pc of an operand tile = its rows 8 pc .. 8 pc + 7 (1 KB)
+    auto dma_piece = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, char* dst, int pc) {
+        const int gr = min(row0 + 8 * pc + drow, nrows - 1);         // rows past the end re-read the last row (never stored)
+        const __bf16* src = base + (int64_t)gr * ld + k0 + 8 * dchunk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    };
+    auto dma_tiles = [&](int k0, char* stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma_piece(prm.x, prm.ldx, m0, M, k0, stage, 2 * w + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, k0, stage + XT, 4 * w + j);
+    };
+    gf32x4 acc[4][4];                                                // [nt][mt]: rows n (registers), column m (lane)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = gf32x4{0, 0, 0, 0};
+    auto mma_k32 = [&](const char* Xs, const char* Ws, int ks) {
+        gbf16x8 af[4], bfm[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const gbf16x8*>(Ws + gsw(64 * wn + 16 * t + r, 4 * ks + q4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bfm[t] = *reinterpret_cast<const gbf16x8*>(Xs + gsw(64 * wm + 16 * t + r, 4 * ks + q4));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfm[mt], acc[nt][mt], 0, 0, 0);
+    };
+    const int KT = K / BK;
+    dma_tiles(0, smem);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE;
+        char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+        if (kt + 1 < KT) dma_tiles((kt + 1) * BK, nxt);
+        mma_k32(cur, cur + XT, 0);
+        mma_k32(cur, cur + XT, 1);
+        __syncthreads();                                             // tile kt+1 landed, tile kt consumed
+    }
+    // ---- LoRA branch: one more 32-deep step over the padded rank (EA rows m0.. -> X image, EB rows n0.. -> W image) -------
+    if (prm.ea && prm.eb) {
+        const int cpr = prm.RP / 8;
+        const gbf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        for (int i = tid; i < BN * 4; i += 512) {
+            const int row = i >> 2, c = i & 3;
+            const int gn = min(n0 + row, N - 1);
+            *reinterpret_cast<gbf16x8*>(smem + XT + gsw(row, c)) =
+                c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.eb + (int64_t)gn * prm.RP + 8 * c) : z;
+            if (row < BM) {
+                const int gm = min(m0 + row, M - 1);
+                *reinterpret_cast<gbf16x8*>(smem + gsw(row, c)) =
+                    c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.ea + (int64_t)gm * prm.RP + 8 * c) : z;
+            }
+        }
+        __syncthreads();
+        mma_k32(smem, smem + XT, 0);
+        __syncthreads();
+    }
+    // ---- epilogue: tile -> LDS as [128 m][256 n] bf16 (512-byte rows, 16-byte chunk index XOR-ed with m & 31), then rows out ---
+    char* ct = smem;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int gn = min(n0 + 64 * wn + 16 * nt + 4 * q4, N - 4);
+        const gf32x4 bias4 = prm.bias ? *reinterpret_cast<const gf32x4*>(prm.bias + gn) : gf32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = 64 * wm + 16 * mt + r, n = 64 * wn + 16 * nt + 4 * q4;
+            const gf32x4 v = acc[nt][mt] + bias4;
+            gbf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            const int chunk = n >> 3;
+            *reinterpret_cast<gbf16x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4) + ((n & 4) << 1)) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < BM * 32; i += 512) {
+        const int m = i >> 5, chunk = i & 31;
+        const int gm = m0 + m, gn = n0 + 8 * chunk;
+        if (gm < M && gn < N) {
+            const gu32x4 v = *reinterpret_cast<const gu32x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
+            *reinterpret_cast<gu32x4*>(prm.y + (int64_t)gm * prm.ldy + gn) = v;
+        }
+    }
+}
+
+static int launch_gemm128(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           g128::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.nbm = (p.M + 127) / 128;
+    p.group_m = 0;
+    hipLaunchKernelGGL(qlora_gemm128_kernel, dim3(p.nbn * p.nbm), dim3(512), g128::LDS_BYTES, stream, p);
+    return (int)hipGetLastError();
+}
+
 // W^T as a dense bf16 matrix [K][N] from the NF4 codes of W [N][K]: the operand of dx = dy . W through the same GEMM kernel
 // (contraction over n needs the weight n-major).  One workgroup = a 64 (n) x 64 (k) tile: 32 bytes of codes per row (one
 // 64-weight block, one scale), decoded into LDS, written out as 64 rows of 128 bytes.  grid = (K/64, N/64), block = 256.
@@ -668,6 +791,11 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
     const int sched = tune_get(TUNE_GEMM_SCHED);
+    // 256 x 256 tiles for at most half of the 256 CUs: 128-row tiles fill the chip in one round (measured: (4096, 2048, 2048)
+    // 0.054 -> 0.044 ms, (2048, 2560, 2048) 0.052 -> 0.035; with 160 tiles, e.g. (4096, 2560, 2048), the 256-row tiles stay
+    // ahead, 0.055 vs 0.068: two rounds of half tiles cost more than one round of whole ones).  Dense weight only;
+    // "gemm_sched" 12 forces them, 13 forbids them.
+    if (!w_is_nf4 && sched != 13 && (sched == 12 || (int64_t)((M + 255) / 256) * ((N + 255) / 256) <= 128)) return launch_gemm128(p, st);
     if (sched == 11) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, false, true>(p, st)
                                      : launch_gemm256<false, false, false, false, 0, false, false, false, true>(p, st);
     if (sched == 9) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, true>(p, st)

@@ -341,8 +341,8 @@ def test_qlora_layer_with_double_quantised_base():
 @pytest.mark.parametrize("M,N,K,rp", [(2048, 2560, 2048, 16), (300, 320, 128, 32), (1000, 64, 448, 16), (513, 1096, 192, 0)])
 @pytest.mark.parametrize("dq", [False, True])
 def test_hand_written_qlora_gemm(M, N, K, rp, dq):
-    """csrc/nf4_gemm.hip (256 x 256 tiles, x by LDS-DMA, bias + LoRA step fused): dense bf16 weight and NF4 codes decoded in
-    the loop, ragged M / N included, against float32 math on the same dequantised weight; and the transposed dequantise."""
+    """csrc/nf4_gemm.hip (256 x 256 tiles, or 128 x 256 when those would leave CUs idle; x by LDS-DMA, bias + LoRA step fused):
+    dense bf16 weight and NF4 codes decoded in the loop, ragged M / N included, against float32 math on the same dequantised weight; and the transposed dequantise."""
     from fastmax_experiments_amd import lora
     g = torch.Generator().manual_seed(M + N + K)
     lin = torch.nn.Linear(K, N)
@@ -357,10 +357,17 @@ def test_hand_written_qlora_gemm(M, N, K, rp, dq):
         ea = (torch.randn(M, rp, generator=g) * 0.1).to(torch.bfloat16).cuda()
         eb = (torch.randn(N, rp, generator=g) * 0.1).to(torch.bfloat16).cuda()
         ref = ref + ea.float() @ eb.float().T
-    y_dense = lora.hip_gemm(x, wd, None, q.bias, ea, eb, N)
+    from fastmax_experiments_amd import _lib
+    y_dense = lora.hip_gemm(x, wd, None, q.bias, ea, eb, N)            # few tiles: the 128-row-tile kernel
+    _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", 13), "tune")   # ... and with it forbidden: 256 x 256 tiles
+    try:
+        y_dense256 = lora.hip_gemm(x, wd, None, q.bias, ea, eb, N)
+    finally:
+        _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", 0), "tune")
     y_nf4 = lora.hip_gemm(x, q.weight.data, scales, q.bias, ea, eb, N)
     assert y_dense.shape == (M, N) and _rel(y_dense, ref) < 1e-2 and _rel(y_nf4, ref) < 1e-2
     assert torch.equal(y_dense, y_nf4)                      # same bf16 weight values either way -> the same bits
+    assert torch.equal(y_dense, y_dense256)                 # same accumulation order per element in both tilings
     if N % 64 == 0 and K % 64 == 0:
         wt = lora._dense_weight_t(q.weight.data, scales, N, K)
         assert torch.equal(wt, wd.t())

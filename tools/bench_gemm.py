@@ -71,7 +71,8 @@ def main():
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
         for sched, label in ((0, "LDS-DMA staging issued in front of the step"), (6, "LDS-DMA pieces between the MFMA groups"),
                              (7, "staging through registers (load, MFMAs, ds_write)"),
-                             (8, "fragments of the next half read under the MFMAs of this one")):
+                             (8, "fragments of the next half read under the MFMAs of this one"),
+                             (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))

@@ -72,7 +72,7 @@ def main():
                 qd_in, kd, vd = qd, kd0.repeat_interleave(rep_, dim=1), vd0.repeat_interleave(rep_, dim=1)
         else:
             qd_in, kd, vd, kf, vf = qd, kd0, vd0, k, v
-        if gk == H and rng.random() < 0.2 and Nq >= 2:
+        if gk == H and rng.random() < 0.2 and 2 <= Nq <= 700 and Nk <= 700:      # (the numpy restatement walks 32-token chunks)
             # linearmax (fastmax_hack.py:5-60), forward: prologue + operator against the oracle's restatement
             desc = f"case {ci}: linearmax {dt} p={p} mask={mask} (B,H,Nq,Nk,D)=({B},{H},{Nq},{Nk},{D}) layouts={kinds}"
             try:

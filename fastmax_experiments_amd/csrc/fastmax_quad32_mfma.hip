@@ -19,6 +19,14 @@
 
 namespace fastmax {
 
+#ifdef FASTMAX_QUAD32_STAMPS
+// diagnostic build only (tools/quad32_stamps.py): per workgroup, wave 0's issue-time split of the D <= 64 tile loop
+__device__ unsigned long long* g_q32_stamps = nullptr;
+#define Q32_STAMP(var) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (var) += now_ - q32_t; q32_t = now_; } while (0)
+#else
+#define Q32_STAMP(var) do { } while (0)
+#endif
+
 struct Quad32Params {
     const void *q, *k, *v;
     Strides3 qs, ks, vs;
@@ -97,6 +105,10 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
         for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
     float gsum[4] = {0.f, 0.f, 0.f, 0.f};
     const float a = prm.a, c2 = 0.5f * prm.a * prm.a;
+#ifdef FASTMAX_QUAD32_STAMPS
+    unsigned long long q32_t = __builtin_amdgcn_s_memtime(), st_qk = 0, st_poly = 0, st_pv = 0, st_adv = 0, st_bar = 0, st_tiles = 0, st_wait = 0, st_commit = 0;
+    const unsigned long long q32_t0 = q32_t;
+#endif
 
     // f(a s) of one S^T tile (32 keys x 32 queries) -> the two B fragments (16 keys each) of the P^T operand
     auto poly = [&](const f32x16& sc, int key0, auto masked_tag, Frag<NPP> (&pf)[2]) {
@@ -224,13 +236,18 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
             // D <= 64 (measured): leaving the two S chains to the compiler and walling only the polynomial off, with the
             // V^T fragments requested ahead of it, is 4 % faster than the grouped issue and needs no spill
             if (!(ABL & 16)) { qk(0); qk(1); }
+            __builtin_amdgcn_sched_barrier(0);
+            Q32_STAMP(st_qk);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 if (!(ABL & 8)) vread(jt);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(ABL & 4)) poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
                 __builtin_amdgcn_sched_barrier(0);
+                Q32_STAMP(st_poly);
                 if (!(ABL & 32)) pv(jt);
+                __builtin_amdgcn_sched_barrier(0);
+                Q32_STAMP(st_pv);
             }
         }
     };
@@ -238,7 +255,15 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     // is requested
     auto advance = [&](int kt) {
         if (kt + 1 < nkt) {
+#ifdef FASTMAX_QUAD32_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // diagnostic: the wait for tile kt+1's loads on its own
+            Q32_STAMP(st_wait);
+#endif
             if (!(ABL & 1)) commit((kt & 1) ^ 1);
+#ifdef FASTMAX_QUAD32_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            Q32_STAMP(st_commit);
+#endif
             if (kt + 2 < nkt && !(ABL & 2)) request(kt + 2);
         }
     };
@@ -254,8 +279,14 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     __syncthreads();
     int kt = 0;
     for (; kt < n_plain; ++kt) {
+        Q32_STAMP(st_bar);
         advance(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        Q32_STAMP(st_adv);
         tile(kt, kt & 1, std::false_type{});
+#ifdef FASTMAX_QUAD32_STAMPS
+        ++st_tiles;
+#endif
         __syncthreads();
     }
     for (; kt < n_act; ++kt) {
@@ -268,6 +299,13 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
         __syncthreads();
     }
 
+#ifdef FASTMAX_QUAD32_STAMPS
+    if (g_q32_stamps && tid == 0) {
+        unsigned long long* rec = g_q32_stamps + 8 * (int64_t)blockIdx.x;
+        rec[0] = st_tiles; rec[1] = st_qk; rec[2] = st_poly; rec[3] = st_pv; rec[4] = st_adv; rec[5] = st_bar;
+        rec[6] = st_wait; rec[7] = st_commit;
+    }
+#endif
     float gs = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
     gs += __shfl_xor(gs, 32, 64);
     // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
@@ -358,3 +396,10 @@ int launch_fwd_quad32(const FwdArgs& a) {
 }
 
 }  // namespace fastmax
+
+#ifdef FASTMAX_QUAD32_STAMPS
+extern "C" int fastmax_hip_debug_quad32_stamps(void* buffer) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buffer);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(fastmax::g_q32_stamps), &p, sizeof(p));
+}
+#endif

@@ -236,7 +236,9 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
             // D <= 64 (measured): leaving the two S chains to the compiler and walling only the polynomial off, with the
             // V^T fragments requested ahead of it, is 4 % faster than the grouped issue and needs no spill
             if (!(ABL & 16)) { qk(0); qk(1); }
+#ifdef FASTMAX_QUAD32_STAMPS
             __builtin_amdgcn_sched_barrier(0);
+#endif
             Q32_STAMP(st_qk);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
@@ -246,7 +248,9 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
                 __builtin_amdgcn_sched_barrier(0);
                 Q32_STAMP(st_poly);
                 if (!(ABL & 32)) pv(jt);
+#ifdef FASTMAX_QUAD32_STAMPS
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 Q32_STAMP(st_pv);
             }
         }
@@ -281,7 +285,9 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     for (; kt < n_plain; ++kt) {
         Q32_STAMP(st_bar);
         advance(kt);
+#ifdef FASTMAX_QUAD32_STAMPS
         __builtin_amdgcn_sched_barrier(0);
+#endif
         Q32_STAMP(st_adv);
         tile(kt, kt & 1, std::false_type{});
 #ifdef FASTMAX_QUAD32_STAMPS

@@ -677,6 +677,383 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm128_kernel(GemmParams prm) {
     }
 }
 
+// ---- experiment ("gemm_sched" 20): the same 256 x 256 x 64 tile with FOUR waves, each owning 128 x 128 (256 accumulator
+// registers: the unified 512-register file at one wave per SIMD), operands staged through registers (global_load_dwordx4 ->
+// ds_write_b128) and every load / store / fragment read interleaved with the matrix instructions of the same wave:
+//   half 0 of step kt: 64 MFMAs on fragments F0 | the 16 ds_writes of tile kt+1 (loaded during the previous half) + the 16
+//                      fragment reads F1 of this tile's second 32-deep half
+//   barrier            tile kt+1 whole in the other stage
+//   half 1:            64 MFMAs on F1 | the 16 global loads of tile kt+2 + the 16 fragment reads F0 of tile kt+1
+// Fewer LDS bytes per flop than the 8-wave form (16 fragment reads per 64 MFMAs instead of 12 per 32) and no LDS-DMA issue cost;
+// dense bf16 weight only.
+namespace g256w4 {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int XT = BM * BK * 2, STAGE = 2 * XT;
+constexpr int LDS_BYTES = 2 * STAGE;                                         // 131072
+}  // namespace g256w4
+
+__global__ __launch_bounds__(256, 1) void qlora_gemm256w4_kernel(GemmParams prm) {
+    using namespace g256w4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 15, q4 = lane >> 4;
+    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    if (prm.group_m > 0) {
+        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
+        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
+        bm = grp * prm.group_m + rem % rows;
+        bn = rem / rows;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int M = prm.M, N = prm.N, K = prm.K;
+    // staging map: piece j of a thread = 16-byte chunk (tid & 7) of tile row (tid >> 3) + 32 j.  Whole tiles only (the host sends
+    // ragged M or N to the 8-wave kernel), so a piece's address is a workgroup-uniform base + ONE per-thread offset: no
+    // per-piece address registers (the 512-register budget is 256 accumulators + 96 fragment + 64 staging registers).
+    const int srow = tid >> 3, sch = tid & 7;
+    const unsigned xoff = (unsigned)(srow * (int)prm.ldx + 8 * sch) * 2u, woff = (unsigned)(srow * K + 8 * sch) * 2u;
+    const char* xblk = reinterpret_cast<const char*>(prm.x + (int64_t)m0 * prm.ldx);
+    const char* wblk = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(prm.w) + (int64_t)n0 * K);
+    const int64_t xstep = 64 * prm.ldx, wstep = 64 * (int64_t)K;     // bytes between pieces (32 rows)
+    const int sdst0 = gsw(srow, sch);                                // piece j lands 32 rows = 4096 bytes further (same swizzle)
+    gu32x4 rx[8], rw[8];
+    auto load_piece = [&](int k0, int j) {                           // j: 0..7 x, 8..15 W
+        if (j < 8) rx[j] = *reinterpret_cast<const gu32x4*>(xblk + j * xstep + 2 * k0 + xoff);
+        else rw[j - 8] = *reinterpret_cast<const gu32x4*>(wblk + (j - 8) * wstep + 2 * k0 + woff);
+    };
+    auto store_piece = [&](char* stage, int j) {
+        if (j < 8) *reinterpret_cast<gu32x4*>(stage + sdst0 + 4096 * j) = rx[j];
+        else *reinterpret_cast<gu32x4*>(stage + XT + sdst0 + 4096 * (j - 8)) = rw[j - 8];
+    };
+    gf32x4 acc[8][8];                                                // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = gf32x4{0, 0, 0, 0};
+    gbf16x8 a0[8], a1[8], b[8];                                      // weight fragments double-buffered, x fragments rotate in place
+    auto frag_a = [&](const char* st, int ks, int t) {
+        return *reinterpret_cast<const gbf16x8*>(st + XT + gsw(128 * wn + 16 * t + r, 4 * ks + q4));
+    };
+    auto frag_b = [&](const char* st, int ks, int t) {
+        return *reinterpret_cast<const gbf16x8*>(st + gsw(128 * wm + 16 * t + r, 4 * ks + q4));
+    };
+    // one 32-deep half: row tile by row tile (mt), 8 MFMAs each.  After row tile mt: b[mt] is refilled with the next half's
+    // fragment and ONE weight fragment of the next half is fetched into the other buffer (so the first row tile after the
+    // barrier finds all its operands long since loaded); `side(2 mt)`, `side(2 mt + 1)` carry the staging traffic.
+    // The MFMAs are in place in the accumulation registers by inline asm: left to the register allocator, the two unrolled
+    // halves get differently numbered accumulators and ~300 v_accvgpr_mov / read / write per K step to line them up again.
+    // With one wave per SIMD nothing else fills the gaps: a 16-cycle MFMA leaves 8 issue cycles, so the side instructions are
+    // spread ONE per pair of MFMAs (clustered behind a row tile they delayed the next MFMA by their whole issue time:
+    // stamps gave 22-27 cycles per MFMA).  b[mt] can only be refilled once its row tile is done: it is refilled two MFMAs into
+    // the NEXT row tile.
+    auto half = [&](const gbf16x8 (&af)[8], gbf16x8 (&afn)[8], const char* nst, int nks, auto&& side) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nt][mt]) : "v"(af[nt]), "v"(b[mt]));
+                if (nt == 1) {
+                    if (mt > 0) b[mt - 1] = frag_b(nst, nks, mt - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (nt == 3) {
+                    afn[mt] = frag_a(nst, nks, mt);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (nt == 5) {
+                    side(2 * mt);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (nt == 7) {
+                    side(2 * mt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        b[7] = frag_b(nst, nks, 7);
+    };
+    const int KT = K / BK;
+    unsigned long long t0c = 0, t0r = 0, tl = 0, st_h0 = 0, st_h1 = 0, st_wait = 0, st_bar = 0;
+    if (prm.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    // prologue: tile 0 through registers into stage 0, tile 1 into registers
+#pragma unroll
+    for (int j = 0; j < 16; ++j) load_piece(0, j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) store_piece(smem, j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) load_piece(min(1, KT - 1) * BK, j);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a0[t] = frag_a(smem, 0, t); b[t] = frag_b(smem, 0, t); }
+    if (prm.stamps) tl = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < KT; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE;
+        char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+        const bool more = kt + 1 < KT;
+        // half 0: F0 = a0; tile kt+1 (in registers) -> nxt; F1 <- cur, second half.  No branches inside the halves: on the last
+        // steps the stores go to a stage nobody reads again and the loads re-read the last tile.
+        half(a0, a1, cur, 1, [&](int j) { store_piece(nxt, j); });
+        if (prm.stamps) {
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long tc = __builtin_amdgcn_s_memtime();
+            st_h0 += ta - tl;  st_wait += tb - ta;  st_bar += tc - tb;  tl = tc;
+        } else {
+            __syncthreads();
+        }
+        // half 1: F1 = a1; tile kt+2 -> registers; F0 <- nxt, first half (a harmless re-read of cur on the last step)
+        const char* nf = more ? nxt : cur;
+        const int k2 = min(kt + 2, KT - 1) * BK;
+        half(a1, a0, nf, 0, [&](int j) { load_piece(k2, j); });
+        if (prm.stamps) { const unsigned long long td = __builtin_amdgcn_s_memtime(); st_h1 += td - tl; tl = td; }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                // the hazard recogniser does not see inside the asm MFMAs
+    if (prm.stamps && tid == 0) {
+        prm.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        prm.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        prm.stamps[4 * blockIdx.x + 2] = st_wait + (st_h0 << 32);   // low word: wait before the barrier; high word: half 0
+        prm.stamps[4 * blockIdx.x + 3] = st_bar + (st_h1 << 32);     // low word: barrier; high word: half 1
+    }
+    __syncthreads();
+    // ---- LoRA branch: one more 32-deep step over the padded rank --------------------------------------------------------------
+    if (prm.ea && prm.eb) {
+        const int cpr = prm.RP / 8;
+        const gbf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        for (int i = tid; i < BM * 4; i += 256) {
+            const int row = i >> 2, c = i & 3;
+            const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
+            *reinterpret_cast<gbf16x8*>(smem + gsw(row, c)) = c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.ea + (int64_t)gm * prm.RP + 8 * c) : z;
+            *reinterpret_cast<gbf16x8*>(smem + XT + gsw(row, c)) = c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.eb + (int64_t)gn * prm.RP + 8 * c) : z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { a0[t] = frag_a(smem, 0, t); b[t] = frag_b(smem, 0, t); }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nt][mt]) : "v"(a0[nt]), "v"(b[mt]));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();
+    }
+    // ---- epilogue: tile -> LDS as [256 m][256 n] bf16, then whole rows out -------------------------------------------------------
+    char* ct = smem;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const int gn = min(n0 + 128 * wn + 16 * nt + 4 * q4, N - 4);
+        const gf32x4 bias4 = prm.bias ? *reinterpret_cast<const gf32x4*>(prm.bias + gn) : gf32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = 128 * wm + 16 * mt + r, n = 128 * wn + 16 * nt + 4 * q4;
+            const gf32x4 v = acc[nt][mt] + bias4;
+            gbf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            const int chunk = n >> 3;
+            *reinterpret_cast<gbf16x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4) + ((n & 4) << 1)) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < BM * 32; i += 256) {
+        const int m = i >> 5, chunk = i & 31;
+        const int gm = m0 + m, gn = n0 + 8 * chunk;
+        if (gm < M && gn < N) {
+            const gu32x4 v = *reinterpret_cast<const gu32x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
+            *reinterpret_cast<gu32x4*>(prm.y + (int64_t)gm * prm.ldy + gn) = v;
+        }
+    }
+}
+
+// ---- experiment ("gemm_sched" 21): the four-wave form on 32 x 32 x 16 MFMAs.  A 32-cycle matrix instruction leaves 24 issue
+// cycles for one ds_write_b128 (13) or a fragment read / global load, where the 16-cycle one leaves 8 and every longer side
+// instruction pushes the next MFMA back.  Images: 128 data bytes + 16 pad bytes per row (conflict-free for 32-row ds_read_b128
+// fragments, which the XOR image is not).  A K step = four 16-deep sub-steps s0..s3 of 16 MFMAs; fragments of sub-step s+1 are
+// read during s; the 16 stores of tile kt+1 are spread over s0..s2, the barrier sits between s2 and s3 (all reads of tile kt are
+// issued before it, so its stage is free for tile kt+2 afterwards), s3 reads tile kt+1's first fragments and issues the 16 loads
+// of tile kt+2.
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+namespace g256w4b {
+constexpr int BM = 256, BN = 256, BK = 64, ROWB = 144;
+constexpr int XT = BM * ROWB, STAGE = 2 * XT;                                // 36864, 73728
+constexpr int LDS_BYTES = 2 * STAGE;                                         // 147456 (the epilogue image needs 131072)
+}  // namespace g256w4b
+
+__global__ __launch_bounds__(256, 1) void qlora_gemm256w4b_kernel(GemmParams prm) {
+    using namespace g256w4b;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    if (prm.group_m > 0) {
+        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
+        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
+        bm = grp * prm.group_m + rem % rows;
+        bn = rem / rows;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int N = prm.N, K = prm.K;
+    const int srow = tid >> 3, sch = tid & 7;
+    const unsigned xoff = (unsigned)(srow * (int)prm.ldx + 8 * sch) * 2u, woff = (unsigned)(srow * K + 8 * sch) * 2u;
+    const char* xblk = reinterpret_cast<const char*>(prm.x + (int64_t)m0 * prm.ldx);
+    const char* wblk = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(prm.w) + (int64_t)n0 * K);
+    const int64_t xstep = 64 * prm.ldx, wstep = 64 * (int64_t)K;
+    const int sdst0 = srow * ROWB + 16 * sch;                        // piece j: 32 rows = 32 * 144 bytes further
+    gu32x4 rx[8], rw[8];
+    auto load_piece = [&](int k0, int j) {
+        if (j < 8) rx[j] = *reinterpret_cast<const gu32x4*>(xblk + j * xstep + 2 * k0 + xoff);
+        else rw[j - 8] = *reinterpret_cast<const gu32x4*>(wblk + (j - 8) * wstep + 2 * k0 + woff);
+    };
+    auto store_piece = [&](char* stage, int j) {
+        if (j < 8) *reinterpret_cast<gu32x4*>(stage + sdst0 + 32 * ROWB * j) = rx[j];
+        else *reinterpret_cast<gu32x4*>(stage + XT + sdst0 + 32 * ROWB * (j - 8)) = rw[j - 8];
+    };
+    gf32x16 acc[4][4];                                               // [nt][mt]: C rows = n (registers), column = m (lane & 31)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragment of 16-deep sub-step s (k = 16 s + 8 h .. + 7): row 32 t + l31 of the wave's 128 rows
+    const int fa0 = XT + (128 * wn + l31) * ROWB + 16 * h, fb0 = (128 * wm + l31) * ROWB + 16 * h;
+    auto frag_a = [&](const char* st, int s_, int t) { return *reinterpret_cast<const gbf16x8*>(st + fa0 + 32 * ROWB * t + 32 * s_); };
+    auto frag_b = [&](const char* st, int s_, int t) { return *reinterpret_cast<const gbf16x8*>(st + fb0 + 32 * ROWB * t + 32 * s_); };
+    gbf16x8 fa[2][4], fb[2][4];
+    // one sub-step: 16 MFMAs on fragment set `c`; gap g (after MFMA g) carries `gap(g)`
+    auto substep = [&](int c, auto&& gap) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[nt][mt]) : "v"(fa[c][nt]), "v"(fb[c][mt]));
+                gap(4 * mt + nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    const int KT = K / BK;
+    unsigned long long t0c = 0, t0r = 0;
+    if (prm.stamps) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) load_piece(0, j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) store_piece(smem, j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) load_piece(min(1, KT - 1) * BK, j);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(smem, 0, t); fb[0][t] = frag_b(smem, 0, t); }
+    for (int kt = 0; kt < KT; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE;
+        char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+        const char* nf = (kt + 1 < KT) ? nxt : cur;
+        const int k2 = min(kt + 2, KT - 1) * BK;
+        // s0: set 0; reads set 1 <- (cur, 1) in gaps 0..7 (even ones: a, odd: b); stores 0..5 in gaps 8..13
+        substep(0, [&](int g) {
+            if (g < 8) { if (g & 1) fb[1][g >> 1] = frag_b(cur, 1, g >> 1); else fa[1][g >> 1] = frag_a(cur, 1, g >> 1); }
+            else if (g < 14) store_piece(nxt, g - 8);
+        });
+        // s1: set 1; reads set 0 <- (cur, 2); stores 6..10
+        substep(1, [&](int g) {
+            if (g < 8) { if (g & 1) fb[0][g >> 1] = frag_b(cur, 2, g >> 1); else fa[0][g >> 1] = frag_a(cur, 2, g >> 1); }
+            else if (g < 13) store_piece(nxt, g - 2);
+        });
+        // s2: set 0; reads set 1 <- (cur, 3); stores 11..15
+        substep(0, [&](int g) {
+            if (g < 8) { if (g & 1) fb[1][g >> 1] = frag_b(cur, 3, g >> 1); else fa[1][g >> 1] = frag_a(cur, 3, g >> 1); }
+            else if (g < 13) store_piece(nxt, g + 3);
+        });
+        __syncthreads();                                             // tile kt+1 whole; every read of tile kt has been issued
+        // s3: set 1; reads set 0 <- (tile kt+1, 0); the 16 loads of tile kt+2, one per gap
+        substep(1, [&](int g) {
+            if (g < 8) { if (g & 1) fb[0][g >> 1] = frag_b(nf, 0, g >> 1); else fa[0][g >> 1] = frag_a(nf, 0, g >> 1); }
+            load_piece(k2, g);
+        });
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (prm.stamps && tid == 0) {
+        prm.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        prm.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        prm.stamps[4 * blockIdx.x + 2] = 0;
+        prm.stamps[4 * blockIdx.x + 3] = 0;
+    }
+    __syncthreads();
+    // ---- LoRA branch: rank padded to 16 or 32 = one or two 16-deep sub-steps ------------------------------------------------------
+    if (prm.ea && prm.eb) {
+        const int cpr = prm.RP / 8;
+        for (int i = tid; i < BM * cpr; i += 256) {
+            const int row = i / cpr, c = i % cpr;
+            *reinterpret_cast<gbf16x8*>(smem + row * ROWB + 16 * c) = *reinterpret_cast<const gbf16x8*>(prm.ea + (int64_t)(m0 + row) * prm.RP + 8 * c);
+            *reinterpret_cast<gbf16x8*>(smem + XT + row * ROWB + 16 * c) = *reinterpret_cast<const gbf16x8*>(prm.eb + (int64_t)(n0 + row) * prm.RP + 8 * c);
+        }
+        __syncthreads();
+        for (int s_ = 0; s_ < prm.RP / 16; ++s_) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(smem, s_, t); fb[0][t] = frag_b(smem, s_, t); }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[nt][mt]) : "v"(fa[0][nt]), "v"(fb[0][mt]));
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();
+    }
+    // ---- epilogue: tile -> LDS as [256 m][256 n] bf16 (512-byte rows, chunk index XOR-ed with m & 31), then whole rows out --------
+    char* ct = smem;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {                             // accumulator elements 4 gq .. + 3: rows n = 8 gq + 4 h + 0..3
+            const int n = 128 * wn + 32 * nt + 8 * gq + 4 * h;
+            const gf32x4 bias4 = prm.bias ? *reinterpret_cast<const gf32x4*>(prm.bias + n0 + n) : gf32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = 128 * wm + 32 * mt + l31;
+                gbf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(acc[nt][mt][4 * gq + i] + bias4[i]);
+                const int chunk = n >> 3;
+                *reinterpret_cast<gbf16x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4) + ((n & 4) << 1)) = o;
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < BM * 32; i += 256) {
+        const int m = i >> 5, chunk = i & 31;
+        const gu32x4 v = *reinterpret_cast<const gu32x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
+        *reinterpret_cast<gu32x4*>(prm.y + (int64_t)(m0 + m) * prm.ldy + n0 + 8 * chunk) = v;
+    }
+}
+
+static int launch_gemm256w4b(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm256w4b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           g256w4b::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.nbm = (p.M + 255) / 256;
+    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;
+    hipLaunchKernelGGL(qlora_gemm256w4b_kernel, dim3(p.nbn * p.nbm), dim3(256), g256w4b::LDS_BYTES, stream, p);
+    return (int)hipGetLastError();
+}
+
+static int launch_gemm256w4(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm256w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           g256w4::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.nbm = (p.M + 255) / 256;
+    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;
+    hipLaunchKernelGGL(qlora_gemm256w4_kernel, dim3(p.nbn * p.nbm), dim3(256), g256w4::LDS_BYTES, stream, p);
+    return (int)hipGetLastError();
+}
+
 static int launch_gemm128(GemmParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -795,6 +1172,8 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     // 0.054 -> 0.044 ms, (2048, 2560, 2048) 0.052 -> 0.035; with 160 tiles, e.g. (4096, 2560, 2048), the 256-row tiles stay
     // ahead, 0.055 vs 0.068: two rounds of half tiles cost more than one round of whole ones).  Dense weight only;
     // "gemm_sched" 12 forces them, 13 forbids them.
+    if (!w_is_nf4 && sched == 20 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4(p, st);
+    if (!w_is_nf4 && sched == 21 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4b(p, st);
     if (!w_is_nf4 && sched != 13 && (sched == 12 || (int64_t)((M + 255) / 256) * ((N + 255) / 256) <= 128)) return launch_gemm128(p, st);
     if (sched == 11) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, false, true>(p, st)
                                      : launch_gemm256<false, false, false, false, 0, false, false, false, true>(p, st);

@@ -72,7 +72,9 @@ def main():
         for sched, label in ((0, "LDS-DMA staging issued in front of the step"), (6, "LDS-DMA pieces between the MFMA groups"),
                              (7, "staging through registers (load, MFMAs, ds_write)"),
                              (8, "fragments of the next half read under the MFMAs of this one"),
-                             (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced")):
+                             (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced"),
+                             (20, "4 waves x 128 x 128, operands through registers, asm MFMAs"),
+                             (21, "4 waves, 32x32x16 MFMAs, padded images")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))

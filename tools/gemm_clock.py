@@ -21,7 +21,7 @@ def main():
     L.fastmax_hip_debug_gemm_stamps.restype = None
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
     stamps = torch.zeros(nwg, 4, dtype=torch.int64, device="cuda")
-    for sched in (0, 9, 11):
+    for sched in (0, 20, 21):
         L.fastmax_hip_tune(b"gemm_sched", sched)
         t_end = time.perf_counter() + 1.0
         n = 0
@@ -39,7 +39,12 @@ def main():
         L.fastmax_hip_debug_gemm_stamps(None)
         cyc = stamps[:, 0].double().median().item()
         ticks = stamps[:, 1].double().median().item()
-        wd, wb = stamps[:, 2].double().median().item() / (K // 64), stamps[:, 3].double().median().item() / (K // 64)
+        lo2, lo3 = (stamps[:, 2] & 0xffffffff).double(), (stamps[:, 3] & 0xffffffff).double()
+        hi2, hi3 = (stamps[:, 2] >> 32).double(), (stamps[:, 3] >> 32).double()
+        wd, wb = lo2.median().item() / (K // 64), lo3.median().item() / (K // 64)
+        if sched == 20:
+            print(f"   4-wave kernel per K step: half 0 {hi2.median().item() / (K // 64):.0f}, wait before barrier {wd:.0f}, barrier {wb:.0f}, "
+                  f"half 1 {hi3.median().item() / (K // 64):.0f}")
         print(f"sched {sched}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.0f} TF/s; main loop {cyc:.0f} cycles = {cyc / (K // 64):.0f} per K step "
               f"(matrix pipe: 2048), of which wave 0 waits {wd:.0f} for its copies + {wb:.0f} at the barrier; in-kernel clock {cyc / ticks * 0.1:.2f} GHz", flush=True)
 

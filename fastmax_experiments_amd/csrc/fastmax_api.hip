@@ -54,6 +54,7 @@ TuneEntry g_tune[TUNE_COUNT] = {
     {"bf16_kernel", "FASTMAX_BF16_KERNEL", 1},
     {"gemm_sched", "FASTMAX_GEMM_SCHED", 0},          // QLoRA GEMM: vector instructions per matrix instruction in the decode steps
     {"gemm_group_m", "FASTMAX_GEMM_GROUP_M", 16},     // QLoRA / head GEMM: row blocks per group of the workgroup -> tile map (0: column blocks fastest over the whole matrix)
+    {"gemm_xcd", "FASTMAX_GEMM_XCD", 1},              // QLoRA / head GEMM tile map: 1 = every XCD owns a contiguous run of tiles, in 8-row-block groups
 };
 bool g_tune_loaded = false;
 void tune_load() {

@@ -104,7 +104,7 @@ int launch_fwd_mfma_p1_v2(const FwdArgs& a, int ablation);
 bool mfma_p1_v2_supported(const FwdArgs& a);
 // Run-time tuning knobs (A/B runs, ablations): read from the FASTMAX_* environment ONCE at first use, afterwards changed
 // only through fastmax_hip_tune(); launch paths read a plain int, never getenv.
-enum TuneKey { TUNE_MFMA_VARIANT = 0, TUNE_BF16_KERNEL = 1, TUNE_GEMM_SCHED = 2, TUNE_GEMM_GROUP_M = 3, TUNE_COUNT };
+enum TuneKey { TUNE_MFMA_VARIANT = 0, TUNE_BF16_KERNEL = 1, TUNE_GEMM_SCHED = 2, TUNE_GEMM_GROUP_M = 3, TUNE_GEMM_XCD = 4, TUNE_COUNT };
 int tune_get(int key);
 int tune_set(const char* name, int value);
 bool mfma_p1_supported(const fastmax_problem& p);

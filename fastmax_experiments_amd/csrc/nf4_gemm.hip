@@ -48,7 +48,7 @@ struct GemmParams {
     int M, N, K, RP;          // RP: 16 or 32 (rank padded)
     int64_t ldx, ldy;
     int nbn;                  // number of 256-column blocks
-    int nbm, group_m;         // number of 256-row blocks; row blocks per group of the workgroup -> tile map (0: none)
+    int nbm, group_m, xcd;    // number of row blocks; row blocks per group of the workgroup -> tile map (0: none); XCD regrouping
     // lm-head + cross entropy epilogues (EPI 1 / 2): the tile is a block of logits that never leaves the chip
     const int64_t* targets;   // [M]
     float* part;              // EPI 1: [M][nbn] (max, sum exp) of the row over this column block
@@ -66,6 +66,36 @@ __constant__ float kGemmNF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526
                                    0.7229568362236023f, 1.0f};
 
 __device__ __forceinline__ int gsw(int row, int chunk) { return row * 128 + (((chunk ^ row) & 7) << 4); }
+
+// workgroup id -> output tile.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own 4 MB L2), so with
+// `xcd` set the ids are first regrouped so that every XCD owns a CONTIGUOUS run of tile numbers; tiles are then numbered in groups
+// of `group_m` row blocks, rows fastest: the ~32 tiles an XCD runs at a time form an 8 x 4 patch -- 12 operand tiles per K step
+// to fetch into that L2 instead of 18 (column blocks fastest over 16 column blocks) or more.
+__device__ __forceinline__ void gemm_tile_of(const GemmParams& prm, int& bm, int& bn) {
+    int id = blockIdx.x;
+    const int nwg = gridDim.x;
+    if (prm.xcd && (nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    bn = id % prm.nbn;
+    bm = id / prm.nbn;
+    if (prm.group_m > 0) {
+        const int per = prm.group_m * prm.nbn, grp = id / per, rem = id % per;
+        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
+        bm = grp * prm.group_m + rem % rows;
+        bn = rem / rows;
+    }
+}
+
+// host: the tile map of a launch.  "gemm_xcd" 1 (default): XCD regrouping + groups of 8 row blocks up to 16 column blocks; else
+// column blocks fastest, in groups of "gemm_group_m" row blocks beyond 16 column blocks
+static void gemm_map(GemmParams& p) {
+    if (tune_get(TUNE_GEMM_XCD) && p.nbn <= 16) {                  // measured: +1.5 % (4096 wide) .. +3.5 % (2560 wide); -1 % at 48 column blocks
+        p.xcd = 1;
+        p.group_m = 8;
+    } else {
+        p.xcd = 0;
+        p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;
+    }
+}
 
 namespace g256 {
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -99,13 +129,8 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     // With many column blocks (the lm-head: 125) that order makes the 256 concurrent tiles two rows of blocks that stream ALL
     // of W per pass; in groups of `group_m` row blocks, rows fastest, the concurrent tiles form a 16 x 16 patch instead
     // (16 + 16 operand blocks per 256 tiles, not 2 + 125).
-    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
-    if (prm.group_m > 0) {
-        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
-        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
-        bm = grp * prm.group_m + rem % rows;
-        bn = rem / rows;
-    }
+    int bn, bm;
+    gemm_tile_of(prm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int M = prm.M, N = prm.N, K = prm.K;
     if (WNF4 && tid < 16) lut[tid] = kGemmNF4[tid];
@@ -585,7 +610,8 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm128_kernel(GemmParams prm) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int r = lane & 15, q4 = lane >> 4;
-    const int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
+    int bn, bm;
+    gemm_tile_of(prm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int M = prm.M, N = prm.N, K = prm.K;
     const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ drow;
@@ -699,13 +725,8 @@ __global__ __launch_bounds__(256, 1) void qlora_gemm256w4_kernel(GemmParams prm)
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 15, q4 = lane >> 4;
-    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
-    if (prm.group_m > 0) {
-        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
-        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
-        bm = grp * prm.group_m + rem % rows;
-        bn = rem / rows;
-    }
+    int bn, bm;
+    gemm_tile_of(prm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int M = prm.M, N = prm.N, K = prm.K;
     // staging map: piece j of a thread = 16-byte chunk (tid & 7) of tile row (tid >> 3) + 32 j.  Whole tiles only (the host sends
@@ -885,13 +906,8 @@ __global__ __launch_bounds__(256, 1) void qlora_gemm256w4b_kernel(GemmParams prm
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    int bn = blockIdx.x % prm.nbn, bm = blockIdx.x / prm.nbn;
-    if (prm.group_m > 0) {
-        const int per = prm.group_m * prm.nbn, grp = blockIdx.x / per, rem = blockIdx.x % per;
-        const int rows = min(prm.group_m, prm.nbm - grp * prm.group_m);
-        bm = grp * prm.group_m + rem % rows;
-        bn = rem / rows;
-    }
+    int bn, bm;
+    gemm_tile_of(prm, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int N = prm.N, K = prm.K;
     const int srow = tid >> 3, sch = tid & 7;
@@ -1035,7 +1051,7 @@ static int launch_gemm256w4b(GemmParams p, hipStream_t stream) {
         attr_set = true;
     }
     p.nbm = (p.M + 255) / 256;
-    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;
+    gemm_map(p);
     hipLaunchKernelGGL(qlora_gemm256w4b_kernel, dim3(p.nbn * p.nbm), dim3(256), g256w4b::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
@@ -1049,7 +1065,7 @@ static int launch_gemm256w4(GemmParams p, hipStream_t stream) {
         attr_set = true;
     }
     p.nbm = (p.M + 255) / 256;
-    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;
+    gemm_map(p);
     hipLaunchKernelGGL(qlora_gemm256w4_kernel, dim3(p.nbn * p.nbm), dim3(256), g256w4::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
@@ -1063,7 +1079,7 @@ static int launch_gemm128(GemmParams p, hipStream_t stream) {
         attr_set = true;
     }
     p.nbm = (p.M + 127) / 128;
-    p.group_m = 0;
+    gemm_map(p);
     hipLaunchKernelGGL(qlora_gemm128_kernel, dim3(p.nbn * p.nbm), dim3(512), g128::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
@@ -1126,7 +1142,7 @@ static int launch_gemm256(GemmParams p, hipStream_t stream) {
     }
     const int nbm = (p.M + 255) / 256;
     p.nbm = nbm;
-    p.group_m = (p.nbn > 16) ? tune_get(TUNE_GEMM_GROUP_M) : 0;       // few column blocks: W stays in L2 whatever the order
+    gemm_map(p);
     hipLaunchKernelGGL(kern, dim3(p.nbn * nbm), dim3(512), g256::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
@@ -1163,7 +1179,7 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
         sc = GemmScale{scales->absmax, scales->absmax_q, scales->absmax2, scales->code2, scales->offset};
     }
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, sc, bias, reinterpret_cast<const __bf16*>(ea),
-                 reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256, 0, 0,
+                 reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256, 0, 0, 0,
                  nullptr, nullptr, nullptr, nullptr, 0.f, 0, g_gemm_stamps};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
@@ -1187,7 +1203,11 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
                                     : launch_gemm256<false, false, false, false, 0, true>(p, st);
     if (!w_is_nf4) {
         if (sched == 5) return launch_gemm256<false, false, true>(p, st);
-        return sched == 6 ? launch_gemm256<false, false, false, true>(p, st) : launch_gemm256<false, false, false>(p, st);
+        if (sched == 6) return launch_gemm256<false, false, false, true>(p, st);
+        if (sched == 14) return launch_gemm256<false, false, false>(p, st);       // round 2's first loop: every wave issues its copies, then reads, then multiplies
+        // default (= "gemm_sched" 10): copies issued by one wave of each SIMD pair, fragments of the next half read under the
+        // MFMAs of this one -- 5-9 % ahead of the plain loop at every fine-tune shape (profiles/r02_qlora_gemm.md), same bits
+        return launch_gemm256<false, false, false, false, 0, false, true, true>(p, st);
     }
     if (sched == 6) return launch_gemm256<true, false, false, true>(p, st);
     // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else
@@ -1219,10 +1239,11 @@ int fastmax_hip_lmhead_ce_forward(const void* x, int64_t ldx, const void* w, con
     float* part = reinterpret_cast<float*>(workspace);
     float* ztgt = part + (int64_t)M * nbn * 2;
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
-                 reinterpret_cast<__bf16*>(logits), M, V, K, 0, ldx, ldz, nbn, 0, 0, targets, part, ztgt, nullptr, 0.f, ignore_index,
+                 reinterpret_cast<__bf16*>(logits), M, V, K, 0, ldx, ldz, nbn, 0, 0, 0, targets, part, ztgt, nullptr, 0.f, ignore_index,
                  nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rc = logits ? launch_gemm256<false, false, false, false, 3>(p, st) : launch_gemm256<false, false, false, false, 1>(p, st);
+    const int rc = logits ? launch_gemm256<false, false, false, false, 3, false, true, true>(p, st)
+                          : launch_gemm256<false, false, false, false, 1, false, true, true>(p, st);
     if (rc) return rc;
     hipLaunchKernelGGL(lmhead_ce_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, ztgt, targets, loss, lse, M, V, nbn,
                        ignore_index);
@@ -1238,9 +1259,9 @@ int fastmax_hip_lmhead_ce_backward(const void* x, int64_t ldx, const void* w, co
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dz)) & 15) return FASTMAX_E_ALIGNMENT;
     if (((ldx * 2) & 15) || ((ldz * 2) & 15)) return FASTMAX_E_ALIGNMENT;
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
-                 reinterpret_cast<__bf16*>(dz), M, V, K, 0, ldx, ldz, (V + 255) / 256, 0, 0, targets, nullptr, nullptr, lse, grad_scale,
+                 reinterpret_cast<__bf16*>(dz), M, V, K, 0, ldx, ldz, (V + 255) / 256, 0, 0, 0, targets, nullptr, nullptr, lse, grad_scale,
                  ignore_index, nullptr};
-    return launch_gemm256<false, false, false, false, 2>(p, reinterpret_cast<hipStream_t>(stream));
+    return launch_gemm256<false, false, false, false, 2, false, true, true>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // W^T [K][N] bf16 from the NF4 codes of W [N][K] (N % 64 == 0, K % 64 == 0, 16-byte aligned)

@@ -69,7 +69,7 @@ def main():
         row("library: x @ Wd^T (weight already dense)", lambda: x @ wd.t())
         row("library route: decode once + x @ Wd^T + addmm(ea, eb) + bias",
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
-        for sched, label in ((0, "LDS-DMA staging issued in front of the step"), (6, "LDS-DMA pieces between the MFMA groups"),
+        for sched, label in ((0, "default loop (copies by one wave of a SIMD pair, fragments read under the MFMAs)"), (14, "first loop of round 2 (every wave: copies, reads, MFMAs)"), (6, "LDS-DMA pieces between the MFMA groups"),
                              (7, "staging through registers (load, MFMAs, ds_write)"),
                              (8, "fragments of the next half read under the MFMAs of this one"),
                              (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced"),

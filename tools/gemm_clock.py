@@ -21,8 +21,9 @@ def main():
     L.fastmax_hip_debug_gemm_stamps.restype = None
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
     stamps = torch.zeros(nwg, 4, dtype=torch.int64, device="cuda")
-    for sched in (0, 20, 21):
+    for sched, xcd in ((0, 0), (0, 1), (10, 0), (10, 1), (20, 0), (20, 1)):
         L.fastmax_hip_tune(b"gemm_sched", sched)
+        L.fastmax_hip_tune(b"gemm_xcd", xcd)
         t_end = time.perf_counter() + 1.0
         n = 0
         torch.cuda.synchronize()
@@ -45,7 +46,7 @@ def main():
         if sched == 20:
             print(f"   4-wave kernel per K step: half 0 {hi2.median().item() / (K // 64):.0f}, wait before barrier {wd:.0f}, barrier {wb:.0f}, "
                   f"half 1 {hi3.median().item() / (K // 64):.0f}")
-        print(f"sched {sched}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.0f} TF/s; main loop {cyc:.0f} cycles = {cyc / (K // 64):.0f} per K step "
+        print(f"sched {sched} xcd {xcd}: {ms:.3f} ms/launch = {2.0 * M * N * K / ms / 1e9:.0f} TF/s; main loop {cyc:.0f} cycles = {cyc / (K // 64):.0f} per K step "
               f"(matrix pipe: 2048), of which wave 0 waits {wd:.0f} for its copies + {wb:.0f} at the barrier; in-kernel clock {cyc / ticks * 0.1:.2f} GHz", flush=True)
 
 

@@ -622,11 +622,15 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm128_kernel(GemmParams prm) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     };
+    // copies issued by one wave of each SIMD pair (w < 4; w and w + 4 share a SIMD): its partner goes straight to the matrix
+    // instructions (the measured winner of the 256-row kernel's loop orders)
     auto dma_tiles = [&](int k0, char* stage) {
+        if (w < 4) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dma_piece(prm.x, prm.ldx, m0, M, k0, stage, 2 * w + j);
+            for (int j = 0; j < 4; ++j) dma_piece(prm.x, prm.ldx, m0, M, k0, stage, 4 * w + j);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, k0, stage + XT, 4 * w + j);
+            for (int j = 0; j < 8; ++j) dma_piece(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, k0, stage + XT, 8 * w + j);
+        }
     };
     gf32x4 acc[4][4];                                                // [nt][mt]: rows n (registers), column m (lane)
 #pragma unroll

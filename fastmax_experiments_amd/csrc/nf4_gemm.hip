@@ -1216,7 +1216,11 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     if (sched == 6) return launch_gemm256<true, false, false, true>(p, st);
     // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else
     // every wave decodes after its matrix instructions
-    return tune_get(TUNE_GEMM_SCHED) == 1 ? launch_gemm256<true, true>(p, st) : launch_gemm256<true, false>(p, st);
+    if (sched == 1) return launch_gemm256<true, true>(p, st);
+    if (sched == 14) return launch_gemm256<true, false>(p, st);
+    // fragments of the next half read under the MFMAs; every wave issues its own x copies (with the decode in the loop the
+    // one-wave-per-pair copies measured no better: 0.217 vs 0.208 ms at (16384, 2560, 2048); plain loop 0.221)
+    return launch_gemm256<true, false, false, false, 0, false, true>(p, st);
 }
 
 // ---- lm-head + cross entropy without the logits (finetune/lora.py:216-219 = GPT.forward's chunked head,

@@ -78,7 +78,7 @@ def main():
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))
-        for sched, label in ((0, "decode after the MFMAs"), (6, "decode words between the MFMA groups"), (7, "x through registers"), (8, "fragments read under the MFMAs")):
+        for sched, label in ((14, "plain loop, decode after the MFMAs"), (0, "default"), (6, "decode words between the MFMA groups"), (7, "x through registers"), (8, "fragments read under the MFMAs")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, NF4 decoded in the loop, {label} (+ bias + LoRA step)",
                 lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb), lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb))

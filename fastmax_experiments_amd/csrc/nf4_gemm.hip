@@ -138,10 +138,23 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
     // ---- x tile by LDS-DMA: instruction j of wave w fills rows 8 (4w + j) .. + 7 (1 KB); lane -> (row, slot) ------------
     const int drow = lane >> 3, dslot = lane & 7;
     const int dchunk = dslot ^ drow;                                 // the row's low three bits are drow (rows come in 8s)
+    bool dma_all_waves = false;
     auto dma_tile = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, char* dst) {
         if constexpr (SPEC) {
             // only one wave of each SIMD pair (w < 4; w and w + 4 share a SIMD) issues the copies, eight pieces per operand:
             // its partner goes straight to the matrix instructions, so the SIMD multiplies while the copies are being issued
+            // (SPEC + STAG, experiment: the weight tile's pieces are shared by all eight waves, 12 / 4 pieces per pair)
+            if (STAG && dma_all_waves) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pc = 4 * w + j, row = 8 * pc + drow;
+                    const int gr = min(row0 + row, nrows - 1);
+                    const __bf16* src = base + (int64_t)gr * ld + k0 + 8 * dchunk;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+                }
+                return;
+            }
             if (w < 4) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -325,7 +338,11 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             if (kt + 2 < KT) {
                 dma_tile(prm.x, prm.ldx, m0, M, (kt + 2) * BK, cur);
                 if constexpr (WNF4) load_codes((kt + 2) * BK);
-                else dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 2) * BK, cur + XT);
+                else {
+                    dma_all_waves = true;
+                    dma_tile(reinterpret_cast<const __bf16*>(prm.w), K, n0, N, (kt + 2) * BK, cur + XT);
+                    dma_all_waves = false;
+                }
             }
             const char* nf = more ? nxt : cur;                       // last step: a harmless re-read instead of a branch per tile
             half(a1, a0, nf, nf + XT, 0, true);
@@ -1195,6 +1212,7 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     if (!w_is_nf4 && sched == 20 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4(p, st);
     if (!w_is_nf4 && sched == 21 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4b(p, st);
     if (!w_is_nf4 && sched != 13 && (sched == 12 || (int64_t)((M + 255) / 256) * ((N + 255) / 256) <= 128)) return launch_gemm128(p, st);
+    if (sched == 15 && !w_is_nf4) return launch_gemm256<false, false, false, false, 0, false, true, true, true>(p, st);
     if (sched == 11) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, false, true>(p, st)
                                      : launch_gemm256<false, false, false, false, 0, false, false, false, true>(p, st);
     if (sched == 9) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, true>(p, st)

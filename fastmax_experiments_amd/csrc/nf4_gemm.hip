@@ -14,6 +14,8 @@
 //   * the LoRA branch is one more 32-deep step on the same accumulators; the tile leaves through LDS as whole 512-byte rows.
 #include "fastmax_common.h"
 
+#include <type_traits>
+
 namespace fastmax {
 
 typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
@@ -608,6 +610,152 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
             *reinterpret_cast<gu32x4*>(prm.y + (int64_t)gm * prm.ldy + gn) = v;
         }
     }
+}
+
+// ---- experiment ("gemm_sched" 16): the default loop with an UNEVEN row split inside the SIMD pairs.  In the default loop the
+// waves that issue the copies (w < 4) are the critical path of a step: 16 LDS-DMA issues (~80 cycles each) + their 64 MFMAs,
+// while their partners only have 64 MFMAs.  Here the copy-issuing wave of a pair owns 7 of its column strip's 16 row tiles and
+// the partner 9 (56 / 72 MFMAs per step).  Dense bf16 weight, plain epilogue (bias + LoRA step).  The body is instantiated
+// twice (7 and 9 row tiles) behind a wave-uniform branch, so every loop is fully unrolled without per-tile predicates.
+template <int MTA>   // row tiles (of 16) of the copy-issuing wave; its partner owns 16 - MTA
+__global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) {
+    using namespace g256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int r = lane & 15, q4 = lane >> 4;
+    int bn, bm;
+    gemm_tile_of(prm, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int M = prm.M, N = prm.N, K = prm.K;
+    const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ drow;
+    const int KT = K / BK;
+    // copies: waves 0-3 only, eight 1 KB pieces of each operand tile per wave
+    auto dma_tile = [&](const __bf16* base, int64_t ld, int row0, int nrows, int k0, char* dst) {
+        if (w < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pc = 8 * w + j, row = 8 * pc + drow;
+                const int gr = min(row0 + row, nrows - 1);
+                const __bf16* src = base + (int64_t)gr * ld + k0 + 8 * dchunk;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const __bf16* wbase = reinterpret_cast<const __bf16*>(prm.w);
+    dma_tile(prm.x, prm.ldx, m0, M, 0, smem);
+    dma_tile(wbase, K, n0, N, 0, smem + XT);
+    __syncthreads();
+    if (KT > 1) {
+        dma_tile(prm.x, prm.ldx, m0, M, BK, smem + STAGE);
+        dma_tile(wbase, K, n0, N, BK, smem + STAGE + XT);
+    }
+    char* ct = smem;                                                 // epilogue image [256 m][256 n] bf16
+    auto body = [&](auto mt_tag) {
+        constexpr int MT = decltype(mt_tag)::value;
+        const int mrow0 = MT == MTA ? 0 : 16 * MTA;                  // rows 0 .. 16 MTA - 1 / the rest
+        gf32x4 acc[4][MT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = gf32x4{0, 0, 0, 0};
+        gbf16x8 a0[4], a1[4], b[MT];
+        auto frag_a = [&](const char* Ws, int ks, int t) { return *reinterpret_cast<const gbf16x8*>(Ws + gsw(64 * wn + 16 * t + r, 4 * ks + q4)); };
+        auto frag_b = [&](const char* Xs, int ks, int t) { return *reinterpret_cast<const gbf16x8*>(Xs + gsw(mrow0 + 16 * t + r, 4 * ks + q4)); };
+        auto half = [&](const gbf16x8 (&af)[4], gbf16x8 (&afn)[4], const char* nst, int nks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) afn[t] = frag_a(nst + XT, nks, t);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                b[mt] = frag_b(nst, nks, mt);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a0[t] = frag_a(smem + XT, 0, t);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) b[t] = frag_b(smem, 0, t);
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt & 1) ^ 1) * STAGE;
+            half(a0, a1, cur, 1);
+            __syncthreads();                                         // tile kt+1 whole in nxt; nobody reads cur any more
+            if (kt + 2 < KT) {
+                dma_tile(prm.x, prm.ldx, m0, M, (kt + 2) * BK, cur);
+                dma_tile(wbase, K, n0, N, (kt + 2) * BK, cur + XT);
+            }
+            half(a1, a0, (kt + 1 < KT) ? nxt : cur, 0);              // last step: a harmless re-read instead of a branch
+        }
+        __syncthreads();
+        // LoRA branch: one more 32-deep step over the padded rank
+        if (prm.ea && prm.eb) {
+            const int cpr = prm.RP / 8;
+            const gbf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            for (int i = tid; i < BM * 4; i += 512) {
+                const int row = i >> 2, c = i & 3;
+                const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
+                *reinterpret_cast<gbf16x8*>(smem + gsw(row, c)) = c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.ea + (int64_t)gm * prm.RP + 8 * c) : z;
+                *reinterpret_cast<gbf16x8*>(smem + XT + gsw(row, c)) = c < cpr ? *reinterpret_cast<const gbf16x8*>(prm.eb + (int64_t)gn * prm.RP + 8 * c) : z;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a0[t] = frag_a(smem + XT, 0, t);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) b[t] = frag_b(smem, 0, t);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[nt], b[mt], acc[nt][mt], 0, 0, 0);
+            __syncthreads();
+        }
+        // tile -> LDS as [256 m][256 n] bf16 (512-byte rows, 16-byte chunk index XOR-ed with m & 31)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int gn = min(n0 + 64 * wn + 16 * nt + 4 * q4, N - 4);
+            const gf32x4 bias4 = prm.bias ? *reinterpret_cast<const gf32x4*>(prm.bias + gn) : gf32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow0 + 16 * mt + r, n = 64 * wn + 16 * nt + 4 * q4;
+                const gf32x4 v = acc[nt][mt] + bias4;
+                gbf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+                const int chunk = n >> 3;
+                *reinterpret_cast<gbf16x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4) + ((n & 4) << 1)) = o;
+            }
+        }
+    };
+    if (wm == 0) body(std::integral_constant<int, MTA>{});
+    else body(std::integral_constant<int, 16 - MTA>{});
+    __syncthreads();
+    for (int i = tid; i < BM * 32; i += 512) {
+        const int m = i >> 5, chunk = i & 31;
+        const int gm = m0 + m, gn = n0 + 8 * chunk;
+        if (gm < M && gn < N) {
+            const gu32x4 v = *reinterpret_cast<const gu32x4*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
+            *reinterpret_cast<gu32x4*>(prm.y + (int64_t)gm * prm.ldy + gn) = v;
+        }
+    }
+}
+
+template <int MTA>
+static int launch_gemm256a(GemmParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm256a_kernel<MTA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           g256::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.nbm = (p.M + 255) / 256;
+    gemm_map(p);
+    hipLaunchKernelGGL(qlora_gemm256a_kernel<MTA>, dim3(p.nbn * p.nbm), dim3(512), g256::LDS_BYTES, stream, p);
+    return (int)hipGetLastError();
 }
 
 // The same product for row counts whose 256 x 256 tiles would leave CUs idle (M = 2048 .. 8192 at the layer widths of the
@@ -1212,6 +1360,9 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     if (!w_is_nf4 && sched == 20 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4(p, st);
     if (!w_is_nf4 && sched == 21 && (M % 256) == 0 && (N % 256) == 0) return launch_gemm256w4b(p, st);
     if (!w_is_nf4 && sched != 13 && (sched == 12 || (int64_t)((M + 255) / 256) * ((N + 255) / 256) <= 128)) return launch_gemm128(p, st);
+    if (sched == 16 && !w_is_nf4) return launch_gemm256a<7>(p, st);
+    if (sched == 17 && !w_is_nf4) return launch_gemm256a<6>(p, st);
+    if (sched == 18 && !w_is_nf4) return launch_gemm256a<5>(p, st);
     if (sched == 15 && !w_is_nf4) return launch_gemm256<false, false, false, false, 0, false, true, true, true>(p, st);
     if (sched == 11) return w_is_nf4 ? launch_gemm256<true, false, false, false, 0, false, false, false, true>(p, st)
                                      : launch_gemm256<false, false, false, false, 0, false, false, false, true>(p, st);
@@ -1227,9 +1378,10 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
         if (sched == 5) return launch_gemm256<false, false, true>(p, st);
         if (sched == 6) return launch_gemm256<false, false, false, true>(p, st);
         if (sched == 14) return launch_gemm256<false, false, false>(p, st);       // round 2's first loop: every wave issues its copies, then reads, then multiplies
-        // default (= "gemm_sched" 10): copies issued by one wave of each SIMD pair, fragments of the next half read under the
-        // MFMAs of this one -- 5-9 % ahead of the plain loop at every fine-tune shape (profiles/r02_qlora_gemm.md), same bits
-        return launch_gemm256<false, false, false, false, 0, false, true, true>(p, st);
+        // default (= "gemm_sched" 16): copies issued by one wave of each SIMD pair, fragments of the next half read under the
+        // MFMAs of this one (5-9 % ahead of the plain loop at every fine-tune shape), and the copy-issuing wave of a pair
+        // owning 7 of the strip's 16 row tiles, its partner 9 (another 2-3 %) -- profiles/r02_qlora_gemm.md; same bits
+        return launch_gemm256a<7>(p, st);
     }
     if (sched == 6) return launch_gemm256<true, false, false, true>(p, st);
     // NF4 in the loop: "gemm_sched" 1 = SIMD partner waves decode / multiply in opposite order (measured 5-10 % slower), else

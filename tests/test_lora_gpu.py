@@ -401,7 +401,7 @@ def test_training_size_qlora_layer_routes_agree(route, monkeypatch):
     assert _rel(x.grad, xa.grad) < 3e-2 and _rel(layer.lora_A.grad, A.grad) < 3e-2 and _rel(layer.lora_B.grad, B.grad) < 3e-2
 
 
-@pytest.mark.parametrize("sched", [8, 9, 11, 14, 15, 20, 21])
+@pytest.mark.parametrize("sched", [8, 9, 10, 11, 14, 15, 17, 18, 20, 21])
 def test_gemm_loop_variants_match_the_default_kernel(sched):
     """the other loop orders of the 256 x 256 GEMM (8 .. 11: fragments read under the MFMAs, copies issued by one wave of a SIMD
     pair, both, staggered copies) and its four-wave forms ("gemm_sched" 20: 16x16x32 MFMAs in place by inline asm, operands

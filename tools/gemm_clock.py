@@ -21,7 +21,7 @@ def main():
     L.fastmax_hip_debug_gemm_stamps.restype = None
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
     stamps = torch.zeros(nwg, 4, dtype=torch.int64, device="cuda")
-    for sched, xcd in ((0, 1), (15, 1), (14, 1)):
+    for sched, xcd in ((0, 1), (16, 1), (17, 1), (18, 1)):
         L.fastmax_hip_tune(b"gemm_sched", sched)
         L.fastmax_hip_tune(b"gemm_xcd", xcd)
         t_end = time.perf_counter() + 1.0

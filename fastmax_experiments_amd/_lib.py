@@ -30,7 +30,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s",
            "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed",
            "fastmax_hip_lmhead_ce_workspace", "fastmax_hip_lmhead_ce_forward", "fastmax_hip_lmhead_ce_backward",
-           "fastmax_hip_debug_gemm_stamps"]
+           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope"]
 
 
 class Problem(ctypes.Structure):
@@ -120,6 +120,8 @@ def lib():
     L.fastmax_hip_lmhead_ce_workspace.argtypes = [ci, ci]
     L.fastmax_hip_lmhead_ce_workspace.restype = i64
     L.fastmax_hip_lmhead_ce_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, i64, vp]
+    L.fastmax_hip_qlora_gemm_rope.argtypes = [vp, i64, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.fastmax_hip_qlora_gemm_rope.restype = ci
     L.fastmax_hip_debug_gemm_stamps.argtypes = [vp]
     L.fastmax_hip_debug_gemm_stamps.restype = None
     L.fastmax_hip_lmhead_ce_forward.restype = ci
@@ -146,7 +148,7 @@ def lib():
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 6:
+    if L.fastmax_hip_abi_version() != 7:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

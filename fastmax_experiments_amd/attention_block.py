@@ -65,9 +65,11 @@ class CausalSelfAttention(nn.Module):
 
     def forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, input_pos=None) -> torch.Tensor:
         B, T, C = x.size()
-        qkv = self.attn(x)
         q_per_kv = self.n_head // self.n_query_groups
         total_qkv = q_per_kv + 2
+        if self._one_kernel_qkv(x, input_pos, B, T, q_per_kv):
+            return self._forward_one_kernel_qkv(x, cos, sin, B, T, q_per_kv)
+        qkv = self.attn(x)
         fused = (self.fused_neighbours and x.device.type == "cuda" and input_pos is None and
                  ops.rope_qkv_supported(qkv.dtype, self.head_size, self.rope_n_elem))
         grouped = (fused and self.attn_alg == "linearmax" and q_per_kv > 1 and torch.is_grad_enabled() and
@@ -104,6 +106,46 @@ class CausalSelfAttention(nn.Module):
             y = fastmax(q, k, v, p=2, mask=mask)                   # model.py:485, minus the .cpu()/.cuda() hops
         y = y.reshape(B, T, self.head_size * self.n_head)          # model.py:453-455 (no transpose: quirk Q3)
         return self.proj(y)
+
+
+# (methods of CausalSelfAttention, kept below forward for readability)
+def _one_kernel_qkv(self, x, input_pos, B, T, q_per_kv) -> bool:
+    """can the qkv projection, the de-interleave and RoPE run as ONE kernel (nf4_gemm.hip's tile epilogue)?  Training-size bf16
+    input on the hand-written GEMM route, whole heads per 256-column tile, and a K / V layout that needs no per-head copies
+    (group views, or one query head per group)"""
+    from . import lora
+    attn = self.attn
+    if not (self.fused_neighbours and self.gemm_rope and x.device.type == "cuda" and input_pos is None and x.dtype == torch.bfloat16):
+        return False
+    if not (isinstance(attn, lora.LoRAQKVLinear) and attn.rope_fusable(x)):
+        return False
+    if q_per_kv > 1 and not self.group_views:
+        return False
+    N, K = attn.linear.out_features, attn.linear.in_features
+    return (ops.rope_qkv_supported(x.dtype, self.head_size, self.rope_n_elem) and
+            lora.gemm_rope_supported(N, K, B * T, T, self.n_query_groups, q_per_kv, self.head_size, self.rope_n_elem))
+
+
+def _forward_one_kernel_qkv(self, x, cos, sin, B, T, q_per_kv):
+    tables16 = cos.dtype == x.dtype and x.dtype in (torch.bfloat16, torch.float16)
+    cos32, sin32 = ops._rope_tables_f32(cos, sin, T, self.rope_n_elem)
+    grouped = (self.attn_alg == "linearmax" and q_per_kv > 1 and torch.is_grad_enabled() and
+               (x.requires_grad or any(p.requires_grad for p in self.attn.parameters())) and
+               grouped_route_supported(x.device, x.dtype, self.head_size, B * self.n_head))
+    expand = (4 if grouped else 3) if q_per_kv > 1 else 0
+    q, k, v = self.attn(x, rope=(cos32, sin32, B, T, self.n_query_groups, q_per_kv, self.head_size, self.rope_n_elem, tables16, expand))
+    if grouped:
+        y = fastmax_hack_grouped(q, k, v, q_per_kv, p=1)
+    elif self.attn_alg == "linearmax":
+        y = fastmax_hack(q, k, v, p=1, mask=True)
+    else:
+        y = fastmax(q, k, v, p=2, mask=True)
+    return self.proj(y.reshape(B, T, self.head_size * self.n_head))
+
+
+CausalSelfAttention._one_kernel_qkv = _one_kernel_qkv
+CausalSelfAttention._forward_one_kernel_qkv = _forward_one_kernel_qkv
+CausalSelfAttention.gemm_rope = True
 
 
 # head shapes of the BASELINE.json configs (lit_gpt/config.py:197-205, 1394-1411, 735-747)

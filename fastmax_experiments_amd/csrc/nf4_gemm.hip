@@ -58,6 +58,12 @@ struct GemmParams {
     const float* lse;         // EPI 2: [M] log sum exp of the row
     float gscale;             // EPI 2: d(loss)/d(row loss)
     int64_t ignore_index;
+    // RoPE + QKV de-interleave epilogue (qlora_gemm256a_kernel<.., true>): the product is the qkv projection of a batch of
+    // sequences (rows = b * T + t; columns = (group, slot, d) of lit_gpt/model.py:397-420) and leaves as q (B, G qpk, T, hs),
+    // k, v (B, G, T, hs) with the rotation of model.py:702-708 applied to the first rope_n elements of the q and k heads
+    const float *rope_cos, *rope_sin;   // (T, rope_n) float32
+    void *rq, *rk, *rv;
+    int T, G, qpk, hs, rope_n, tables16;
     unsigned long long* stamps;   // diagnostics: [workgroup][4] = main loop (shader cycles, 100 MHz ticks), wave 0's wait for its copies, for the barrier; null normally
 };
 
@@ -617,7 +623,15 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256_kernel(GemmParams prm) {
 // while their partners only have 64 MFMAs.  Here the copy-issuing wave of a pair owns 7 of its column strip's 16 row tiles and
 // the partner 9 (56 / 72 MFMAs per step).  Dense bf16 weight, plain epilogue (bias + LoRA step).  The body is instantiated
 // twice (7 and 9 row tiles) behind a wave-uniform branch, so every loop is fully unrolled without per-tile predicates.
-template <int MTA>   // row tiles (of 16) of the copy-issuing wave; its partner owns 16 - MTA
+// x cos + y sin with the reference's three float32 roundings (no fused multiply-add), as fastmax_rope.hip
+__device__ __forceinline__ float gemm_rope_mul_add(float x, float c, float y, float s_) {
+#pragma clang fp contract(off)
+    const float p0 = x * c;
+    const float p1 = y * s_;
+    return p0 + p1;
+}
+
+template <int MTA, bool ROPE = false>   // MTA: row tiles (of 16) of the copy-issuing wave; its partner owns 16 - MTA
 __global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) {
     using namespace g256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -733,6 +747,47 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) 
     if (wm == 0) body(std::integral_constant<int, MTA>{});
     else body(std::integral_constant<int, 16 - MTA>{});
     __syncthreads();
+    if constexpr (ROPE) {
+        // the tile holds, per token row, whole heads of the qkv projection (256 % hs == 0): every 16-byte piece goes to its
+        // (q | k | v, head, token) row; pieces of the rotated range of a q or k head are combined with their partner piece
+        // (d <-> d +- rope_n / 2) from the same LDS row first -- the values are the bf16-rounded outputs, so the result is
+        // bit-identical to the separate pass of fastmax_rope.hip over a stored qkv tensor
+        // a thread keeps its 16-byte column piece for all 16 rows it visits (i += 512: row += 16): head, slot, offset in the
+        // head, partner piece and destination tensor are computed once; only (batch, token) advance
+        const int hs = prm.hs, total = prm.qpk + 2, half = prm.rope_n >> 1, H = prm.G * prm.qpk;
+        const int chunk = tid & 31, f = n0 + 8 * chunk;
+        if (f < N) {
+            const int hd = f / hs, d = f - hd * hs;
+            const int g = hd / total, slot = hd - g * total;
+            const bool rotate = slot <= prm.qpk && d < prm.rope_n, first = d < half;
+            const int pchunk = first ? chunk + (half >> 3) : chunk - (half >> 3);
+            const int heads = slot < prm.qpk ? H : prm.G, head = slot < prm.qpk ? g * prm.qpk + slot : g;
+            __bf16* const dbase = reinterpret_cast<__bf16*>(slot < prm.qpk ? prm.rq : (slot == prm.qpk ? prm.rk : prm.rv)) + d;
+            int m = tid >> 5;
+            int b = (m0 + m) / prm.T, t = (m0 + m) - b * prm.T;
+            for (; m < BM && m0 + m < M; m += 16) {
+                gbf16x8 xo = *reinterpret_cast<const gbf16x8*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
+                if (rotate) {
+                    const gbf16x8 xp = *reinterpret_cast<const gbf16x8*>(ct + m * 512 + (((pchunk ^ m) & 31) << 4));
+                    const gf32x4* cs = reinterpret_cast<const gf32x4*>(prm.rope_cos + (int64_t)t * prm.rope_n + d);
+                    const gf32x4* sn = reinterpret_cast<const gf32x4*>(prm.rope_sin + (int64_t)t * prm.rope_n + d);
+                    const gf32x4 c0 = cs[0], c1 = cs[1], s0 = sn[0], s1 = sn[1];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a = (float)xo[e], pb = first ? -(float)xp[e] : (float)xp[e];
+                        const float c = e < 4 ? c0[e & 3] : c1[e & 3], s_ = e < 4 ? s0[e & 3] : s1[e & 3];
+                        // first half: x[d] cos[d] - x[d + half] sin[d];  second: x[d] cos[d] + x[d - half] sin[d]   (model.py:702-708)
+                        const float o = prm.tables16 ? (float)(__bf16)(a * c) + (float)(__bf16)(pb * s_) : gemm_rope_mul_add(a, c, pb, s_);
+                        xo[e] = (__bf16)o;
+                    }
+                }
+                *reinterpret_cast<gbf16x8*>(dbase + (((int64_t)b * heads + head) * prm.T + t) * hs) = xo;
+                t += 16;
+                if (t >= prm.T) { t -= prm.T; ++b; }
+            }
+        }
+        return;
+    }
     for (int i = tid; i < BM * 32; i += 512) {
         const int m = i >> 5, chunk = i & 31;
         const int gm = m0 + m, gn = n0 + 8 * chunk;
@@ -743,18 +798,18 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) 
     }
 }
 
-template <int MTA>
+template <int MTA, bool ROPE = false>
 static int launch_gemm256a(GemmParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm256a_kernel<MTA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qlora_gemm256a_kernel<MTA, ROPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            g256::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     p.nbm = (p.M + 255) / 256;
     gemm_map(p);
-    hipLaunchKernelGGL(qlora_gemm256a_kernel<MTA>, dim3(p.nbn * p.nbm), dim3(512), g256::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((qlora_gemm256a_kernel<MTA, ROPE>), dim3(p.nbn * p.nbm), dim3(512), g256::LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1349,7 +1404,7 @@ int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_n
     }
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, sc, bias, reinterpret_cast<const __bf16*>(ea),
                  reinterpret_cast<const __bf16*>(eb), reinterpret_cast<__bf16*>(y), M, N, K, rank_pad, ldx, ldy, (N + 255) / 256, 0, 0, 0,
-                 nullptr, nullptr, nullptr, nullptr, 0.f, 0, g_gemm_stamps};
+                 nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, g_gemm_stamps};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // dense weight: "gemm_sched" 5 = the L2-prefetch form (measured 5-9 % slower than the plain two-stage loop: kept for A/B)
     const int sched = tune_get(TUNE_GEMM_SCHED);
@@ -1418,7 +1473,7 @@ int fastmax_hip_lmhead_ce_forward(const void* x, int64_t ldx, const void* w, con
     float* ztgt = part + (int64_t)M * nbn * 2;
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
                  reinterpret_cast<__bf16*>(logits), M, V, K, 0, ldx, ldz, nbn, 0, 0, 0, targets, part, ztgt, nullptr, 0.f, ignore_index,
-                 nullptr};
+                 nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rc = logits ? launch_gemm256<false, false, false, false, 3, false, true, true>(p, st)
                           : launch_gemm256<false, false, false, false, 1, false, true, true>(p, st);
@@ -1438,8 +1493,35 @@ int fastmax_hip_lmhead_ce_backward(const void* x, int64_t ldx, const void* w, co
     if (((ldx * 2) & 15) || ((ldz * 2) & 15)) return FASTMAX_E_ALIGNMENT;
     GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr, nullptr, nullptr,
                  reinterpret_cast<__bf16*>(dz), M, V, K, 0, ldx, ldz, (V + 255) / 256, 0, 0, 0, targets, nullptr, nullptr, lse, grad_scale,
-                 ignore_index, nullptr};
+                 ignore_index, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr};
     return launch_gemm256<false, false, false, false, 2, false, true, true>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The qkv projection of an attention sub-layer with its neighbours fused into the tile's way out (SURVEY.md 8f row 1 inside
+// the ★ row): y = x W^T + bias + ea eb^T is never stored as (tokens, qkv features); every 16-byte piece of the finished tile
+// goes to q (B, G q_per_kv, T, hs) / k, v (B, G, T, hs), the first rope_n elements of the q and k heads rotated
+// (lit_gpt/model.py:397-425, 702-708).  x rows are b * T + t.  Dense bf16 weight [N][K], N == G (q_per_kv + 2) hs,
+// 256 % hs == 0, rope_n % 16 == 0, K % 64 == 0; tables16: the caller's rope cache was 16-bit (products rounded before the sum).
+int fastmax_hip_qlora_gemm_rope(const void* x, int64_t ldx, const void* w, const float* bias, const void* ea, const void* eb,
+                                int rank_pad, const float* cos, const float* sin, void* q, void* k, void* v, int M, int N, int K,
+                                int T, int G, int q_per_kv, int head_size, int rope_n_elem, int tables16, void* stream) {
+    if (!x || !w || !cos || !sin || !q || !k || !v) return FASTMAX_E_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || T <= 0 || (M % T) || G <= 0 || q_per_kv <= 0 || head_size <= 0) return FASTMAX_E_BAD_SHAPE;
+    if (N != G * (q_per_kv + 2) * head_size || (256 % head_size) || rope_n_elem < 0 || rope_n_elem > head_size || (rope_n_elem % 16))
+        return FASTMAX_E_BAD_SHAPE;
+    if ((ea == nullptr) != (eb == nullptr)) return FASTMAX_E_NULL;
+    if (ea && rank_pad != 16 && rank_pad != 32) return FASTMAX_E_BAD_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return FASTMAX_E_ALIGNMENT;
+    if ((ldx * 2) & 15) return FASTMAX_E_ALIGNMENT;
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return FASTMAX_E_ALIGNMENT;
+    if (ea && ((reinterpret_cast<uintptr_t>(ea) | reinterpret_cast<uintptr_t>(eb)) & 15)) return FASTMAX_E_ALIGNMENT;
+    GemmParams p{reinterpret_cast<const __bf16*>(x), w, GemmScale{nullptr, nullptr, nullptr, nullptr, 0.f}, bias,
+                 reinterpret_cast<const __bf16*>(ea), reinterpret_cast<const __bf16*>(eb), nullptr, M, N, K, rank_pad, ldx, 0,
+                 (N + 255) / 256, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0, cos, sin, q, k, v, T, G, q_per_kv, head_size,
+                 rope_n_elem, tables16 ? 1 : 0, nullptr};
+    return launch_gemm256a<7, true>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // W^T [K][N] bf16 from the NF4 codes of W [N][K] (N % 64 == 0, K % 64 == 0, 16-byte aligned)

@@ -499,13 +499,40 @@ def _dense_weight_t(wq, scales, N, K):
     return buf[: N * K].view(K, N)
 
 
+def hip_gemm_rope(x2, w, bias, ea, eb, N, cos32, sin32, B, T, G, qpk, hs, rope_n, tables16):
+    """the qkv projection straight into q (B, G qpk, T, hs) and k, v (B, G, T, hs) with RoPE applied: one kernel
+    (fastmax_hip_qlora_gemm_rope); x2: (B T, K) rows b * T + t, w: dense bf16 (N, K)"""
+    M, K = x2.shape
+    q = torch.empty((B, G * qpk, T, hs), dtype=torch.bfloat16, device=x2.device)
+    k = torch.empty((B, G, T, hs), dtype=torch.bfloat16, device=x2.device)
+    v = torch.empty((B, G, T, hs), dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device):
+        rc = _lib.lib().fastmax_hip_qlora_gemm_rope(x2.data_ptr(), x2.stride(0), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                    None if ea is None else ea.data_ptr(), None if eb is None else eb.data_ptr(),
+                                                    0 if ea is None else ea.shape[1], cos32.data_ptr(), sin32.data_ptr(),
+                                                    q.data_ptr(), k.data_ptr(), v.data_ptr(), M, N, K, T, G, qpk, hs, rope_n,
+                                                    1 if tables16 else 0, _stream(x2.device))
+    _lib.check(rc, "fastmax_hip_qlora_gemm_rope")
+    return q, k, v
+
+
+def gemm_rope_supported(N, K, M, T, G, qpk, hs, rope_n) -> bool:
+    """shapes the fused qkv projection + RoPE epilogue takes (the 256 x 256-tile kernel: more than 128 tiles, whole heads
+    per tile); FASTMAX_GEMM_ROPE=0 turns it off"""
+    return (os.environ.get("FASTMAX_GEMM_ROPE", "1") != "0" and QLORA_ROUTE == "gemm" and N == G * (qpk + 2) * hs and 256 % hs == 0
+            and rope_n % 16 == 0 and K % 64 == 0 and M % T == 0 and ((M + 255) // 256) * ((N + 255) // 256) > 128)
+
+
 class _QLoRAGemmFn(torch.autograd.Function):
     """y = x deq(W)^T + bias + (x A^T) eb^T with every product in libfastmax_hip.so (lit_gpt/lora.py:170-177, 419-433 and
     their autograd mirror, without dropout): the frozen product and dx by the 256 x 256-tile GEMM with the LoRA branch as
     its last step, x A^T / dy eb by lora_down, dA / dB by lora_tn."""
 
     @staticmethod
-    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused):
+    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused, rope=None):
+        """rope = (cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand): the product is an attention sub-layer's qkv
+        projection and leaves the kernel as (q, k, v) -- de-interleaved and rotated, in the layout of ops.RopeQKVSplit's
+        `expand` mode 0 (k, v at their G heads; also mode 1 when qpk == 1), 3 or 4 (stride-0 group views) -- instead of y"""
         R, RP = A.shape[0], ebt.shape[0]
         ctx.scales = scales
         if R == RP:
@@ -515,18 +542,35 @@ class _QLoRAGemmFn(torch.autograd.Function):
             abt[:R] = A.detach()
         ea, eat = lora_down(x2, abt)
         eb = ebt.t().contiguous()                                  # (N, RP): the B-side operand of the GEMM's last step
+        ctx.save_for_backward(x2, eat, abt, ebt, wq)
+        ctx.dims = (N, K, R, A.dtype)
+        ctx.rope = rope
+        if rope is not None:
+            cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand = rope
+            w = wdense if wdense is not None else _dense_weight(wq, scales, N, K)
+            q, k, v = hip_gemm_rope(x2, w, bias, ea, eb, N, cos32, sin32, B, T, G, qpk, hs, rope_n, tables16)
+            if expand in (3, 4):                                      # ops.RopeQKVSplit's group views: nothing is copied
+                kv = lambda t: t.view(B * G, 1, T, hs).expand(B * G, qpk, T, hs)
+                return q.view(B * G, qpk, T, hs), (kv(k) if expand == 3 else k), kv(v)
+            return q, k, v
         if fused and wdense is None:
             y = hip_gemm(x2, wq, scales, bias, ea, eb, N)
         else:
             y = hip_gemm(x2, wdense if wdense is not None else _dense_weight(wq, scales, N, K), None, bias, ea, eb, N)
-        ctx.save_for_backward(x2, eat, abt, ebt, wq)
-        ctx.dims = (N, K, R, A.dtype)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *more):
         x2, eat, abt, ebt, wq = ctx.saved_tensors
         N, K, R, a_dt = ctx.dims
+        if ctx.rope is not None:
+            # gradients of q (B, G qpk, T, hs), k, v (B, G, T, hs): inverse rotation + re-interleave in one pass, then as before
+            from . import ops
+            cos32, sin32, B, T, G, qpk, hs, rope_n, _, expand = ctx.rope
+            # modes 3 / 4: the gradients of the stride-0 views arrive dense, one per query head, and the pass sums a group
+            # while it reads them -- exactly ops.RopeQKVSplit.backward
+            dy = ops.rope_qkv_backward(dy, more[0], more[1], cos32, sin32, B, T, G, qpk, hs, rope_n,
+                                       {0: 0, 1: 0, 3: 1, 4: 2}[expand]).view(B * T, N)
         dy = dy.contiguous()
         dx = dA = d_ebt = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -538,7 +582,7 @@ class _QLoRAGemmFn(torch.autograd.Function):
             dA = lora_tn(d_eat, x2, R, a_dt)
         if ctx.needs_input_grad[2]:
             d_ebt = lora_tn(eat, dy, dtype=torch.bfloat16)
-        return dx, dA, d_ebt, None, None, None, None, None, None, None
+        return dx, dA, d_ebt, None, None, None, None, None, None, None, None
 
 
 class _QLoRAThinFn(torch.autograd.Function):
@@ -590,7 +634,7 @@ def thin_route(x: torch.Tensor, base: "NF4Linear") -> bool:
     return M >= DENSE_M or base._dense_cache is not None
 
 
-def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
+def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None):
     """x: (..., K) bf16 device tensor; A: (r, K); ebt: (RP, N) bf16 operand of the branch (scaling applied, rank zero padded)."""
     N, K = base.out_features, base.in_features
     if K % 128 or N % 64:
@@ -603,6 +647,8 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt):
         bias = bias.float()
     scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
+        if rope is not None:
+            return _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, False, rope)
         y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused")
     else:
         y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache)
@@ -718,13 +764,20 @@ class LoRALinear(LoRALayer):
     def _lora_enabled(self) -> bool:
         return self.r > 0 and not self.merged
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def rope_fusable(self, x: torch.Tensor) -> bool:
+        """would forward(x, rope=...) take the one-kernel route (qkv projection + de-interleave + RoPE)?"""
+        if not (self._lora_enabled() and isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD):
+            return False
+        no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
+        return no_dropout and thin_route(x, self.linear) and QLORA_ROUTE == "gemm"
+
+    def forward(self, x: torch.Tensor, rope=None) -> torch.Tensor:
         if not self._lora_enabled():
             return self.linear(x)
         if isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD:
             no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
             if no_dropout and thin_route(x, self.linear):
-                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t())
+                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope)
             ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
             return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
         pretrained = self.linear(x)

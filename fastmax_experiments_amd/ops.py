@@ -237,6 +237,19 @@ def _rope_tables_f32(cos, sin, T, n_elem):
     return c, s_
 
 
+def rope_qkv_backward(gq, gk, gv, cos32, sin32, B, T, G, qpk, hs, rope_n, kern_expand):
+    """gradient of the QKV split + RoPE pass: (B,T,G,qpk+2,hs) from the gradients of q, k, v (inverse rotation, re-interleave;
+    kern_expand 1 / 2: k, v (or v) arrive per query head and are summed over their group while they are read)"""
+    gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
+    gqkv = torch.empty((B, T, G, qpk + 2, hs), dtype=gq.dtype, device=gq.device)
+    with torch.cuda.device(gq.device):
+        rc = _lib.lib().fastmax_hip_rope_qkv_split_backward(gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), cos32.data_ptr(),
+                                                            sin32.data_ptr(), gqkv.data_ptr(), B, T, G, qpk, hs, rope_n, kern_expand,
+                                                            _DT[gq.dtype], _stream(gq.device))
+    _lib.check(rc, "fastmax_hip_rope_qkv_split_backward")
+    return gqkv
+
+
 class RopeQKVSplit(torch.autograd.Function):
     """qkv (B,T,G,q_per_kv+2,hs) -> q (B,H,T,hs), k, v (B,H,T,hs): de-interleave + RoPE + GQA expand in one HIP pass
     (fastmax_rope.hip; lit_gpt/model.py:397-425), and the mirror pass for the gradient."""

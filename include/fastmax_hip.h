@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 6   /* 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 7   /* 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -268,6 +268,16 @@ int fastmax_hip_nf4_dequantize_s(const uint8_t* wq, const fastmax_nf4_scales* sc
 int fastmax_hip_qlora_gemm(const void* x, int64_t ldx, const void* w, int w_is_nf4, const fastmax_nf4_scales* scales,
                            const float* bias, const void* ea, const void* eb, int rank_pad, void* y, int64_t ldy,
                            int M, int N, int K, void* stream);
+
+/*      The qkv projection with its neighbours fused into the tile's way out: y = x W^T + bias + ea eb^T is never stored as
+ *      (tokens, qkv features); the finished 256 x 256 tile is written as q (B, G q_per_kv, T, hs) and k, v (B, G, T, hs) with the
+ *      rotation of lit_gpt/model.py:702-708 on the first rope_n_elem elements of the q and k heads -- lit_gpt/lora.py:419-433
+ *      followed by model.py:397-425 in one kernel, bit-identical to fastmax_hip_qlora_gemm + fastmax_hip_rope_qkv_split.
+ *      x rows are b * T + t; dense bf16 weight [N][K]; N == G (q_per_kv + 2) head_size; 256 % head_size == 0;
+ *      rope_n_elem % 16 == 0; K % 64 == 0; cos, sin (T, rope_n_elem) float32; tables16 as in fastmax_hip_rope_qkv_split.     */
+int fastmax_hip_qlora_gemm_rope(const void* x, int64_t ldx, const void* w, const float* bias, const void* ea, const void* eb,
+                                int rank_pad, const float* cos, const float* sin, void* q, void* k, void* v, int M, int N, int K,
+                                int T, int G, int q_per_kv, int head_size, int rope_n_elem, int tables16, void* stream);
 
 /*      W^T as dense bf16 [K][N] from the codes of W [N][K]: the weight operand of dx = dy . W through fastmax_hip_qlora_gemm
  *      (x := dy, w := W^T, M x K output).  N % 64 == 0, K % 64 == 0.                                                       */

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.fastmax_hip_abi_version() == 6
+    assert lib.fastmax_hip_abi_version() == 7
     assert b"p should be 1 or 2" in lib.fastmax_hip_error_string(-1)
     assert lib.fastmax_hip_error_string(0) == b"ok"
 

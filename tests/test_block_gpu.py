@@ -437,3 +437,32 @@ def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
         finals.append(torch.cat([p.detach().float().reshape(-1) for p in params]).clone())
     assert losses[0] == losses[1]
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("config,T,alg", [("tiny-llama-1.1b", 2048, "fastmax"), ("tiny-llama-1.1b", 2048, "linearmax"),
+                                          ("Llama-2-7b-hf", 1024, "fastmax")])
+def test_one_kernel_qkv_projection_matches_the_separate_passes(config, T, alg):
+    """the qkv projection with the de-interleave and RoPE in its tile epilogue (fastmax_hip_qlora_gemm_rope) against the same
+    layer with the separate QKV-split + RoPE pass: the epilogue rotates the bf16-rounded outputs exactly like the separate
+    kernel, so the sub-layer's output and every gradient must be bit-identical"""
+    from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache
+    torch.manual_seed(3)
+    blk = CausalSelfAttention(attn_alg=alg, r=8, alpha=16, **CONFIG_SHAPES[config]).to(torch.bfloat16)
+    torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
+    blk.quantize_base().cuda()
+    B = 4 if config.startswith("tiny") else 8
+    cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    x = torch.randn(B, T, blk.attn.linear.in_features, device="cuda", dtype=torch.bfloat16)
+    gy = torch.randn_like(x)
+    res = []
+    for one_kernel in (True, False):
+        blk.gemm_rope = one_kernel
+        xa = x.clone().requires_grad_(True)
+        assert blk._one_kernel_qkv(xa, None, B, T, blk.n_head // blk.n_query_groups) == one_kernel
+        y = blk(xa, cos, sin)
+        y.backward(gy)
+        res.append((y.detach().clone(), xa.grad.clone(), blk.attn.lora_A.grad.clone(), blk.attn.lora_B.grad.clone()))
+        blk.attn.lora_A.grad = blk.attn.lora_B.grad = None
+    blk.gemm_rope = True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -439,9 +439,9 @@ def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
     assert torch.equal(finals[0], finals[1])
 
 
-@pytest.mark.parametrize("config,T,alg", [("tiny-llama-1.1b", 2048, "fastmax"), ("tiny-llama-1.1b", 2048, "linearmax"),
-                                          ("Llama-2-7b-hf", 1024, "fastmax")])
-def test_one_kernel_qkv_projection_matches_the_separate_passes(config, T, alg):
+@pytest.mark.parametrize("config,T,alg,tables16", [("tiny-llama-1.1b", 2048, "fastmax", False), ("tiny-llama-1.1b", 2048, "linearmax", False),
+                                                   ("Llama-2-7b-hf", 1024, "fastmax", False), ("tiny-llama-1.1b", 1024, "linearmax", True)])
+def test_one_kernel_qkv_projection_matches_the_separate_passes(config, T, alg, tables16):
     """the qkv projection with the de-interleave and RoPE in its tile epilogue (fastmax_hip_qlora_gemm_rope) against the same
     layer with the separate QKV-split + RoPE pass: the epilogue rotates the bf16-rounded outputs exactly like the separate
     kernel, so the sub-layer's output and every gradient must be bit-identical"""
@@ -450,8 +450,10 @@ def test_one_kernel_qkv_projection_matches_the_separate_passes(config, T, alg):
     blk = CausalSelfAttention(attn_alg=alg, r=8, alpha=16, **CONFIG_SHAPES[config]).to(torch.bfloat16)
     torch.nn.init.normal_(blk.attn.lora_B, std=0.02)
     blk.quantize_base().cuda()
-    B = 4 if config.startswith("tiny") else 8
+    B = 8 if T == 1024 else 4
     cos, sin = build_rope_cache(T, blk.rope_n_elem, device="cuda")
+    if tables16:                                                     # a "bf16-true" rope cache: products rounded before the sum
+        cos, sin = cos.to(torch.bfloat16), sin.to(torch.bfloat16)
     x = torch.randn(B, T, blk.attn.linear.in_features, device="cuda", dtype=torch.bfloat16)
     gy = torch.randn_like(x)
     res = []

@@ -752,26 +752,34 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) 
         // (q | k | v, head, token) row; pieces of the rotated range of a q or k head are combined with their partner piece
         // (d <-> d +- rope_n / 2) from the same LDS row first -- the values are the bf16-rounded outputs, so the result is
         // bit-identical to the separate pass of fastmax_rope.hip over a stored qkv tensor
-        // a thread keeps its 16-byte column piece for all 16 rows it visits (i += 512: row += 16): head, slot, offset in the
-        // head, partner piece and destination tensor are computed once; only (batch, token) advance
+        // thread -> (token row, 16-byte offset d inside a head); it visits the 256 / hs heads of the tile that share this row:
+        // the rotation's cos / sin pieces depend on (token, d) only, so they are loaded ONCE per row and serve every head
+        // (fetched per piece they are four times the bytes of the data).  d, rotate / partner and the per-head destinations are
+        // thread constants (the row advances by 512 / (hs / 8) per visit).
         const int hs = prm.hs, total = prm.qpk + 2, half = prm.rope_n >> 1, H = prm.G * prm.qpk;
-        const int chunk = tid & 31, f = n0 + 8 * chunk;
-        if (f < N) {
-            const int hd = f / hs, d = f - hd * hs;
-            const int g = hd / total, slot = hd - g * total;
-            const bool rotate = slot <= prm.qpk && d < prm.rope_n, first = d < half;
-            const int pchunk = first ? chunk + (half >> 3) : chunk - (half >> 3);
-            const int heads = slot < prm.qpk ? H : prm.G, head = slot < prm.qpk ? g * prm.qpk + slot : g;
-            __bf16* const dbase = reinterpret_cast<__bf16*>(slot < prm.qpk ? prm.rq : (slot == prm.qpk ? prm.rk : prm.rv)) + d;
-            int m = tid >> 5;
-            int b = (m0 + m) / prm.T, t = (m0 + m) - b * prm.T;
-            for (; m < BM && m0 + m < M; m += 16) {
+        const int cph = hs >> 3, nh = 256 / hs;                       // 16-byte chunks per head; heads per tile row (2 or 4 or 8)
+        const int j = tid % cph, d = 8 * j;
+        const bool in_rope = d < prm.rope_n, first = d < half;
+        const int pj = first ? j + (half >> 3) : j - (half >> 3);
+        for (int m = tid / cph; m < BM && m0 + m < M; m += 512 / cph) {
+            const int gm = m0 + m;
+            const int b = gm / prm.T, t = gm - b * prm.T;
+            gf32x4 c0 = {0, 0, 0, 0}, c1 = c0, s0 = c0, s1 = c0;
+            if (in_rope) {
+                const gf32x4* cs = reinterpret_cast<const gf32x4*>(prm.rope_cos + (int64_t)t * prm.rope_n + d);
+                const gf32x4* sn = reinterpret_cast<const gf32x4*>(prm.rope_sin + (int64_t)t * prm.rope_n + d);
+                c0 = cs[0]; c1 = cs[1]; s0 = sn[0]; s1 = sn[1];
+            }
+            for (int hh = 0; hh < nh; ++hh) {
+                const int f = n0 + hh * hs + d;
+                if (f >= N) break;
+                const int hd = f / hs;                                // = n0 / hs + hh
+                const int g = hd / total, slot = hd - g * total;
+                const int chunk = hh * cph + j;
                 gbf16x8 xo = *reinterpret_cast<const gbf16x8*>(ct + m * 512 + (((chunk ^ m) & 31) << 4));
-                if (rotate) {
+                if (in_rope && slot <= prm.qpk) {
+                    const int pchunk = hh * cph + pj;
                     const gbf16x8 xp = *reinterpret_cast<const gbf16x8*>(ct + m * 512 + (((pchunk ^ m) & 31) << 4));
-                    const gf32x4* cs = reinterpret_cast<const gf32x4*>(prm.rope_cos + (int64_t)t * prm.rope_n + d);
-                    const gf32x4* sn = reinterpret_cast<const gf32x4*>(prm.rope_sin + (int64_t)t * prm.rope_n + d);
-                    const gf32x4 c0 = cs[0], c1 = cs[1], s0 = sn[0], s1 = sn[1];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float a = (float)xo[e], pb = first ? -(float)xp[e] : (float)xp[e];
@@ -781,9 +789,10 @@ __global__ __launch_bounds__(512, 1) void qlora_gemm256a_kernel(GemmParams prm) 
                         xo[e] = (__bf16)o;
                     }
                 }
-                *reinterpret_cast<gbf16x8*>(dbase + (((int64_t)b * heads + head) * prm.T + t) * hs) = xo;
-                t += 16;
-                if (t >= prm.T) { t -= prm.T; ++b; }
+                __bf16* dst = slot < prm.qpk ? reinterpret_cast<__bf16*>(prm.rq) + (((int64_t)b * H + g * prm.qpk + slot) * prm.T + t) * hs
+                            : (slot == prm.qpk ? reinterpret_cast<__bf16*>(prm.rk) : reinterpret_cast<__bf16*>(prm.rv)) +
+                                  (((int64_t)b * prm.G + g) * prm.T + t) * hs;
+                *reinterpret_cast<gbf16x8*>(dst + d) = xo;
             }
         }
         return;

@@ -305,7 +305,7 @@ def _dense_weight(wq, scales, N, K):
 
 class _QLoRALinearFn(torch.autograd.Function):
     """y = x deq(W)^T + bias + ea eb^T.  Few rows: all in one HIP kernel (dx through the same dequant GEMM).  Many rows
-    (M >= DENSE_M, bf16): HIP dequant to scratch + library GEMMs.  d(ea), d(eb) are thin library GEMMs."""
+    (M >= DENSE_M, bf16): HIP decode into the scratch + the tile GEMM.  d(ea), d(eb): the streaming rank-r kernels."""
 
     @staticmethod
     def forward(ctx, x2, ea, eb, wq, scales, bias, N, K, wdense=None):
@@ -362,10 +362,23 @@ class _QLoRALinearFn(torch.autograd.Function):
             _lib.check(rc, "fastmax_hip_nf4_linear_backward_input_s")
         if ea is not None:
             dyb = dy.to(torch.bfloat16)
-            if ctx.needs_input_grad[1]:
-                d_ea = dyb @ eb                       # (M,N)(N,32): thin GEMM, library call
-            if ctx.needs_input_grad[2]:
-                d_eb = dyb.t() @ ea                   # (N,M)(M,32)
+            RP = ea.shape[1]
+            thin = (LORA_THIN and dyb.is_cuda and RP in (16, 32) and N % 64 == 0 and ea.dtype == torch.bfloat16 and
+                    eb.dtype == torch.bfloat16 and dyb.stride(1) == 1 and (dyb.stride(0) * 2) % 16 == 0 and dyb.data_ptr() % 16 == 0)
+            if thin:
+                # the rank-r products of the backward pass as streaming HIP kernels (lora_thin.hip), one pass over dy each
+                if ctx.needs_input_grad[1]:
+                    d_ea, _ = lora_down(dyb, eb.t().contiguous(), want_t=False)          # (M, RP) = dy eb
+                if ctx.needs_input_grad[2]:
+                    MP = (M + 15) // 16 * 16
+                    eat = torch.zeros((RP, MP), dtype=torch.bfloat16, device=dyb.device)
+                    eat[:, :M] = ea.t()
+                    d_eb = lora_tn(eat, dyb, dtype=torch.bfloat16, transpose=True)       # (N, RP) = dy^T ea
+            else:
+                if ctx.needs_input_grad[1]:
+                    d_ea = dyb @ eb                   # shapes the thin kernels do not take: tensor ops
+                if ctx.needs_input_grad[2]:
+                    d_eb = dyb.t() @ ea
         return dx, d_ea, d_eb, None, None, None, None, None, None
 
 

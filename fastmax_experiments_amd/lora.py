@@ -558,6 +558,7 @@ class _QLoRAGemmFn(torch.autograd.Function):
         ctx.save_for_backward(x2, eat, abt, ebt, wq)
         ctx.dims = (N, K, R, A.dtype)
         ctx.rope = rope
+        ctx.dense_base = wdense if wq is None else None           # a dense frozen base: its own weight serves dx
         if rope is not None:
             cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand = rope
             w = wdense if wdense is not None else _dense_weight(wq, scales, N, K)
@@ -590,7 +591,8 @@ class _QLoRAGemmFn(torch.autograd.Function):
             d_ea, d_eat = lora_down(dy, ebt)
         if ctx.needs_input_grad[0]:
             # dx = dy W + d_ea abt: the GEMM over n with W^T as its weight operand and the LoRA step (d_ea, abt^T)
-            dx = hip_gemm(dy, _dense_weight_t(wq, ctx.scales, N, K), None, None, d_ea, abt.t().contiguous(), K)
+            wt = ctx.dense_base.t().contiguous() if ctx.dense_base is not None else _dense_weight_t(wq, ctx.scales, N, K)
+            dx = hip_gemm(dy, wt, None, None, d_ea, abt.t().contiguous(), K)
         if ctx.needs_input_grad[1]:
             dA = lora_tn(d_eat, x2, R, a_dt)
         if ctx.needs_input_grad[2]:
@@ -658,6 +660,10 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
+    if not isinstance(base, NF4Linear):
+        # a dense bf16 frozen base (LoRA without quantisation, lit_gpt/lora.py:170-177): the same tile GEMM on the weight itself
+        y = _QLoRAGemmFn.apply(x2, A, ebt, None, None, bias, N, K, base.weight.data, False, rope)
+        return y if rope is not None else y.reshape(*x.shape[:-1], N)
     scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
         if rope is not None:
@@ -779,8 +785,10 @@ class LoRALinear(LoRALayer):
 
     def rope_fusable(self, x: torch.Tensor) -> bool:
         """would forward(x, rope=...) take the one-kernel route (qkv projection + de-interleave + RoPE)?"""
-        if not (self._lora_enabled() and isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD):
+        if not (self._lora_enabled() and self.lora_A.shape[0] <= RANK_PAD):
             return False
+        if not isinstance(self.linear, NF4Linear):
+            return self._dense_base_on_tile_gemm(x)
         no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
         return no_dropout and thin_route(x, self.linear) and QLORA_ROUTE == "gemm"
 
@@ -793,9 +801,24 @@ class LoRALinear(LoRALayer):
                 return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope)
             ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
             return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
+        if self._dense_base_on_tile_gemm(x):
+            return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope)
         pretrained = self.linear(x)
         lora = (self.lora_dropout(x) @ self.lora_A.transpose(0, 1).to(x.dtype)) @ self._dense_rows().transpose(0, 1).to(x.dtype)
         return pretrained + lora * self.scaling
+
+    def _dense_base_on_tile_gemm(self, x: torch.Tensor) -> bool:
+        """a dense (unquantised) frozen bf16 base at training row counts: the hand-written tile GEMM with the LoRA branch and
+        the bias fused, like the NF4 route after its decode (FASTMAX_DENSE_LORA_GEMM=0: tensor ops, as the reference)"""
+        lin = self.linear
+        if isinstance(lin, NF4Linear) or not isinstance(lin, nn.Linear) or os.environ.get("FASTMAX_DENSE_LORA_GEMM", "1") == "0":
+            return False
+        no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
+        M = x.numel() // x.shape[-1]
+        w = lin.weight
+        return (no_dropout and LORA_THIN and QLORA_ROUTE == "gemm" and x.device.type == "cuda" and x.dtype == torch.bfloat16
+                and w.dtype == torch.bfloat16 and not w.requires_grad and w.is_contiguous() and M >= DENSE_M
+                and self.lora_A.shape[0] <= RANK_PAD and lin.in_features % 128 == 0 and lin.out_features % 64 == 0)
 
 
 class LoRAQKVLinear(LoRALinear):

@@ -430,3 +430,34 @@ def test_gemm_loop_variants_match_the_default_kernel(sched):
         assert torch.equal(got, want)
     else:                                                             # 16-deep instead of 32-deep products: another summation order
         assert _rel(got, want) < 4e-3
+
+
+@pytest.mark.parametrize("kind", ["linear", "qkv"])
+def test_dense_base_lora_layers_on_the_tile_gemm(kind, monkeypatch):
+    """LoRA on an UNQUANTISED frozen bf16 base (finetune/lora.py without --quantize; lit_gpt/lora.py:170-177, 419-433) at a
+    training row count: the hand-written tile GEMM with bias + LoRA step fused (dx through W^T, dA / dB by the rank-r kernels)
+    against the tensor-op form of the same layer"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(11)
+    if kind == "linear":
+        layer = lora.LoRALinear(256, 384, r=8, lora_alpha=16, bias=True)
+    else:
+        layer = lora.LoRAQKVLinear(256, (8 + 4) * 32, n_head=8, n_query_groups=2, r=8, lora_alpha=16, enable_lora=(True, False, True),
+                                   bias=False)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer = layer.to(torch.bfloat16).cuda()
+    lora.mark_only_lora_as_trainable(layer)
+    x = torch.randn(2, 1500, 256, device="cuda", dtype=torch.bfloat16)
+    gy = None
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FASTMAX_DENSE_LORA_GEMM", flag)
+        xa = x.clone().requires_grad_(True)
+        assert layer._dense_base_on_tile_gemm(xa) == (flag == "1")
+        y = layer(xa)
+        gy = torch.randn_like(y) if gy is None else gy
+        y.backward(gy)
+        res.append((y.detach().float(), xa.grad.float(), layer.lora_A.grad.float().clone(), layer.lora_B.grad.float().clone()))
+        layer.lora_A.grad = layer.lora_B.grad = None
+    for got, want in zip(*res):
+        assert float((got - want).abs().max()) <= 3e-2 * float(want.abs().max())

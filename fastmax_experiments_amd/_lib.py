@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfastmax_hip.so")
+# FASTMAX_LIB_PATH: A/B runs of tools/ against another build of the same library (never a different implementation)
+LIB_PATH = os.environ.get("FASTMAX_LIB_PATH") or os.path.join(HERE, "libfastmax_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 PATH_AUTO, PATH_QUADRATIC, PATH_RECURRENT, PATH_MFMA, PATH_QUADRATIC_MFMA = 0, 1, 2, 3, 4

@@ -14,6 +14,10 @@ SOURCES = ["fastmax_api.hip", "fastmax_generic.hip", "fastmax_normalize.hip", "f
     "fastmax_quad32_mfma.hip", "fastmax_quad_mfma_bwd.hip", "fastmax_quad32_bwd.hip", "fastmax_mfma_bwd_lin.hip", "fastmax_decode.hip", "nf4_lora.hip", "nf4_gemm.hip", "lora_thin.hip"]
 HEADERS = ["fastmax_common.h", "fastmax_mfma_common.h", "fastmax_mfma32_common.h", os.path.join("..", "..", "include", "fastmax_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+# per-source flags.  The p=2 tile kernels interleave their per-score vector work with MFMAs: packed-f32 instructions
+# (v_pk_fma_f32 / v_pk_add_f32, which the SLP vectoriser forms from adjacent scalar operations) cost 3-4x their issue slot
+# beside matrix instructions on gfx950, so those files are built without it.
+FILE_FLAGS = {"fastmax_quad32_mfma.hip": ["-fno-slp-vectorize"], "fastmax_quad32_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -32,7 +36,7 @@ def stale():
 
 def _compile_one(args):
     cc, src, obj, extra, verbose = args
-    cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + extra + ["-c", src, "-o", obj]
+    cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + FILE_FLAGS.get(src, []) + extra + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

@@ -144,6 +144,8 @@ bool quad_mfma_bwd_supported(const fastmax_problem& p);
 int launch_bwd_quad32(const BwdArgs& a);
 int launch_bwd_quad32_main(const BwdArgs& a);
 bool quad32_bwd_supported(const fastmax_problem& p);
+bool quad32_bwd_layout_ok(const BwdArgs& a);
+size_t quad32_bwd_gt_offset(const fastmax_problem& p);
 int launch_bwd_lin(const BwdArgs& a);
 int launch_bwd_scan(const BwdArgs& a);
 bool scan_bwd_supported(const fastmax_problem& p);

@@ -460,7 +460,12 @@ static int launch_bwd_d(const BwdArgs& a, const BwdParams& prm) {
     if (D <= 64) return launch_bwd_t<T, 64>(a, prm);
     return launch_bwd_t<T, 128>(a, prm);
 }
-size_t bwd_quadratic_workspace(const fastmax_problem& p) { return sizeof(float) * (size_t)p.B * p.H * p.Nq; }
+// c (B,H,Nq) floats; the 32x32-tile kernels add gt = w G (B,H,Nq,D) in the input dtype behind it (fastmax_quad_mfma_bwd.hip)
+size_t quad32_bwd_gt_offset(const fastmax_problem& p) { return (sizeof(float) * (size_t)p.B * p.H * p.Nq + 255) & ~(size_t)255; }
+size_t bwd_quadratic_workspace(const fastmax_problem& p) {
+    if (!quad32_bwd_supported(p)) return sizeof(float) * (size_t)p.B * p.H * p.Nq;
+    return quad32_bwd_gt_offset(p) + (size_t)p.B * p.H * p.Nq * p.D * (p.in_dtype == FASTMAX_F32 ? 4 : 2);
+}
 
 int launch_bwd_quadratic(const BwdArgs& a) {
     if (a.workspace_bytes < bwd_quadratic_workspace(a.prob) || !a.workspace) return FASTMAX_E_WORKSPACE;

@@ -11,6 +11,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(const bf16x8 a, const bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// first product of an accumulation chain that starts at the constant 1.0: the compiler folds an inline-constant C
+// operand only when the constant has a single use, so the instruction is written out.  hipcc pads nothing around an asm
+// statement: `s_nop 1` covers a vector-ALU write of an operand just before it (e.g. an accumulator-file read), and the
+// trailing `s_nop 11` (12 wait states, an 8-pass result) covers ANY reader of the result -- the next MFMA of the chain
+// would need none, but in a kernel whose accumulators live in the AGPR half of the file the compiler moves the result
+// with v_accvgpr_write, or spills it, without knowing a matrix instruction produced it.  The pad is free in a chain: the
+// dependent MFMA cannot start before this one has left the pipe (32 cycles).
+__device__ __forceinline__ f32x16 mfma32_c1(const bf16x8 a, const bf16x8 b) {
+    f32x16 d;
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 1.0\n\ts_nop 11" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int NA, int NB>
+__device__ __forceinline__ f32x16 mfma32_parts_c1(const Frag<NA>& a, const Frag<NB>& b) {
+    f32x16 c = mfma32_c1(a.p[0], b.p[0]);
+    if constexpr (NA == 2) c = mfma32(a.p[1], b.p[0], c);
+    if constexpr (NB == 2) c = mfma32(a.p[0], b.p[1], c);
+    return c;
+}
 template <int NA, int NB>
 __device__ __forceinline__ f32x16 mfma32_parts(const Frag<NA>& a, const Frag<NB>& b, f32x16 c) {
     c = mfma32(a.p[0], b.p[0], c);
@@ -62,6 +81,67 @@ __device__ __forceinline__ Frag<InTraits<TIN>::NP> load_q_frag(const TIN* base, 
     return f;
 }
 
+
+// The same fragment with every element multiplied by `scale` first.  Exact for bf16 data when scale is a power of two
+// (the caller's condition for using it on single-part operands); split operands are scaled in fp32 before the split.
+template <typename TIN>
+__device__ __forceinline__ Frag<InTraits<TIN>::NP> load_q_frag_scaled(const TIN* base, int64_t sn, int row, int nrows, int col0, int D, float scale) {
+    constexpr int EPL = InTraits<TIN>::EPL, NP = InTraits<TIN>::NP;
+    float x[8];
+    if constexpr (EPL == 4) {
+        float lo4[4], hi4[4];
+        piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4, D), lo4);
+        piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 4 + 1, D), hi4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = lo4[i]; x[4 + i] = hi4[i]; }
+    } else {
+        piece_to_float<TIN>(load_piece<TIN>(base, sn, row, nrows, col0 / 8, D), x);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] *= scale;
+    Frag<NP> f;
+    if constexpr (NP == 1) {
+        f.p[0] = cat4(to_bf16x4(f32x4{x[0], x[1], x[2], x[3]}), to_bf16x4(f32x4{x[4], x[5], x[6], x[7]}));
+    } else {
+        bf16x4 h0, l0, h1, l1;
+        split4(f32x4{x[0], x[1], x[2], x[3]}, h0, l0);
+        split4(f32x4{x[4], x[5], x[6], x[7]}, h1, l1);
+        f.p[0] = cat4(h0, h1);
+        f.p[1] = cat4(l0, l1);
+    }
+    return f;
+}
+
+// 64-row tiles of one (b,h) slab of a (N, D) tensor through a buffer descriptor (staging map: row = srow + ps*RPP,
+// 16-byte piece scol).  The record count is the slab's own byte range, so rows past the tensor read as zero in
+// hardware (the range check covers the VGPR offset, which is why the tile offset is added there and not passed as the
+// scalar offset); lanes of a padded head column carry an offset that is always out of range.  A request costs NPASS
+// loads + NPASS integer adds, no compares.  The caller guarantees the slab spans less than 2 GiB (quad32_span_ok).
+template <typename TIN, int NPASS, int RPP>
+struct BufTileLoader {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[NPASS];
+    int tile_bytes;
+    __device__ __forceinline__ BufTileLoader(const TIN* base, int64_t sn, int nrows, int D, int srow, int scol) {
+        constexpr int EPL = InTraits<TIN>::EPL;
+        const int row_bytes = (int)sn * (int)sizeof(TIN);
+        const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(base), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+            voff[ps] = scol * EPL < D ? (srow + ps * RPP) * row_bytes + scol * 16 : (int)0x80000000;
+        tile_bytes = 64 * row_bytes;
+    }
+    __device__ __forceinline__ void load(int tile, u32x4 (&r)[NPASS]) const {
+        const int t = tile * tile_bytes;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ps] + t, 0, 0);
+    }
+};
+// host side: the byte range of one (b,h) slab fits the 31-bit offsets above
+inline bool quad32_span_ok(int64_t sn, int nrows, int D, int elem_bytes) {
+    return sn >= 0 && ((int64_t)(nrows > 0 ? nrows - 1 : 0) * sn + D) * elem_bytes < (int64_t)0x40000000;
+}
 
 // Write a wave's transposed accumulator tiles (acc[dt][i]: column 32dt + row(i) of tensor row first_row + (lane&31))
 // times `scale` (per lane = per tensor row) as whole row segments, 32 rows x 32 columns at a time through a

@@ -1,8 +1,8 @@
 // fastmax backward (dQ, dK, dV; p = 1, 2; masked / unmasked) on 32x32x16 bf16 MFMA tiles (gfx950).
 //
 // Same dense gradients as fastmax_quad_mfma_bwd.hip (reference: attention_mechanisms/fastmax.py:383-691):
-//   s_ij = a q_i.k_j,  P = f(s),  w_i = 1/g_i,  c_i = G_i.o_i,  u_ij = G_i.v_j
-//   dS_ij = (u_ij - c_i) w_i f'(s_ij)        (only j <= i when causal)
+//   x_ij = a q_i.k_j,  P = f(x),  w_i = 1/g_i,  c_i = G_i.o_i,  u_ij = G_i.v_j
+//   dS_ij = (u_ij - c_i) w_i f'(x_ij)        (only j <= i when causal)
 //   dQ_i = a sum_j dS_ij k_j ;  dK_j = a sum_i dS_ij q_i ;  dV_j = sum_i P_ij w_i G_i
 // in the structure of fastmax_quad32_mfma.hip: a wave owns 32 rows of the output (queries for dQ, keys for dK / dV),
 // its own operand rows sit in registers as B fragments (loaded once from global memory), the other side streams
@@ -10,17 +10,30 @@
 // registers as the B operand of the second product.  An LDS tile that is read by rows for one product and
 // transposed for another (K for dQ; Q and G for dK / dV) uses the dual-use XOR image (img_off<DP, 3>).
 // Scores are recomputed in both kernels, so there are no atomics and the result is bitwise reproducible.
+//
+// Round 3: the per-score vector work is folded into the matrix products.
+//   * the prep pass hands over gt_i = w_i G_i (input dtype) and cw_i = c_i w_i, so (u_ij - c_i) w_i = gt_i.v_j - cw_i is
+//     what the U chain delivers when its accumulator starts at -cw_i (a per-lane constant tile for dQ, four 16-byte LDS
+//     reads per 32-query half for dK / dV), and dV_j = sum_i P_ij gt_i needs no row factor
+//   * the S chain starts at u0 and delivers s = u0 + (scaled) q.k with f'(x) = e1 s and f(x) = e2 (s s + u0 u0) (p = 2)
+//     or f = e1 s, f' = 1 (p = 1); the constants e1, e2 leave through the epilogue's per-row scale.  UNIT: the wave's own
+//     rows (Q for dQ, K for dK / dV) are scaled by a on load and u0 is the inline constant 1.0, e1 = 1, e2 = 1/2;
+//     otherwise u0 = 1/a in a register tile, e1 = a, e2 = a a / 2 (single-part operands whose a is not a power of two)
+//   per score element: dQ one multiply (p = 2) or nothing (p = 1) + half a pack; dK / dV one fma + one multiply + one
+//   pack (p = 2) or one pack (p = 1) -- against 3.5 and 7 before; no packed-f32 instructions (built without SLP).
+//   * streamed tiles ride on buffer descriptors (BufTileLoader): no bounds compares, four integer adds per tile request
 #include "fastmax_mfma32_common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
 namespace fastmax {
 
 struct Quad32BwdParams {
-    const void *q, *k, *v, *go;
-    const float *g, *c;             // g (B,H,Nq) from the forward, c_i = G_i.o_i (B,H,Nq) from bwd_prep
-    Strides3 qs, ks, vs, gos;
+    const void *q, *k, *v, *gt;     // gt = w G (B,H,Nq,D) contiguous, input dtype (prep pass)
+    const float* cw;                // c_i w_i (B,H,Nq) from the prep pass
+    Strides3 qs, ks, vs;
     void *dq, *dk, *dv;
     int H, BH, Nq, Nk, D, causal, grad_dtype, nblk;
     float a;
@@ -56,9 +69,16 @@ template <int NPP> __device__ __forceinline__ void pack_tile(const float (&x)[16
     }
 }
 
+// first product of the S chain (accumulator starts at u0: inline 1.0 when UNIT, the register tile otherwise)
+template <int NP, bool UNIT>
+__device__ __forceinline__ f32x16 s_chain_head(const Frag<NP>& a, const Frag<NP>& b, const f32x16& cinit) {
+    if constexpr (UNIT) return mfma32_parts_c1<NP, NP>(a, b);
+    else return mfma32_parts<NP, NP>(a, b, cinit);
+}
+
 // ---- dQ: one wave = 32 queries, NW waves per workgroup, loop over 64-key tiles ---------------------------------------------
 // MB = minimum workgroups per CU the register allocation must allow (2 -> 256 registers at NW = 4; 1 -> the whole file)
-template <int DP, int P, typename TIN, int NW, int MB>
+template <int DP, int P, typename TIN, int NW, int MB, bool UNIT>
 __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
     constexpr int NT = 64 * NW, QT = 32 * NW;
@@ -80,22 +100,27 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
-    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)hh * prm.gos.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.gt) + (int64_t)bh * Nq * D;
     const int srow = tid / COLS, scol = tid % COLS;
 
     Frag<NP> qf[KS], gf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if constexpr (P == 2) qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
-        gf[ks] = load_q_frag<TIN>(gb, prm.gos.sn, myq, Nq, 16 * ks + 8 * h, D);
+        if constexpr (P == 2) {
+            if constexpr (UNIT) qf[ks] = load_q_frag_scaled<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D, prm.a);
+            else qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+        }
+        gf[ks] = load_q_frag<TIN>(gb, D, myq, Nq, 16 * ks + 8 * h, D);
     }
     const int qc = myq < Nq ? myq : Nq - 1;
-    const float wi = 1.0f / prm.g[(int64_t)bh * Nq + qc];
-    const float ncw = -prm.c[(int64_t)bh * Nq + qc] * wi;                 // (u - c) w = u w + ncw
-    const float a = prm.a;
+    const float ncw = -prm.cw[(int64_t)bh * Nq + qc];
+    f32x16 ucinit, scinit;                                                // scinit is dead when UNIT or p = 1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ucinit[i] = ncw; scinit[i] = 1.0f / prm.a; }
+    const int klim = causal ? min(myq, Nk - 1) : Nk - 1;
 
     u32x4 rk[NPASS], rv[NPASS];
-    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
+    const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
     auto request = [&](int kt) {
         kload.load(kt, rk);
         vload.load(kt, rv);
@@ -123,8 +148,6 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
         for (int jt = 0; jt < 2; ++jt) {
             f32x16 sc, u;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; u[i] = 0.f; }
-#pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag<NP> kf, vf;
 #pragma unroll
@@ -132,19 +155,17 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
                     vf.p[p] = ld_row8<DP, 3>(smem, VI + p * IMG, 32 * jt + l31, 2 * ks + h);
                     if constexpr (P == 2) kf.p[p] = ld_row8<DP, 3>(smem, KI + p * IMG, 32 * jt + l31, 2 * ks + h);
                 }
-                u = mfma32_parts<NP, NP>(vf, gf[ks], u);                       // u[j][i] = v_j . G_i
-                if constexpr (P == 2) sc = mfma32_parts<NP, NP>(kf, qf[ks], sc);   // s[j][i] = k_j . q_i
+                // u[j][i] = v_j . gt_i - cw_i ;  s[j][i] = u0 + k_j . q_i
+                u = mfma32_parts<NP, NP>(vf, gf[ks], ks == 0 ? ucinit : u);
+                if constexpr (P == 2) sc = ks == 0 ? s_chain_head<NP, UNIT>(kf, qf[0], scinit) : mfma32_parts<NP, NP>(kf, qf[ks], sc);
             }
             float ds[16];
+            const int rel = klim - (k0 + 32 * jt) - 4 * h;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float x = fmaf(u[i], wi, ncw);
-                if constexpr (P == 2) x *= fmaf(sc[i], a, 1.0f);
-                if constexpr (MASKED) {
-                    const int key = k0 + 32 * jt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const bool keep = key < Nk && (!causal || key <= myq);
-                    x = keep ? x : 0.f;
-                }
+                float x = u[i];
+                if constexpr (P == 2) x *= sc[i];
+                if constexpr (MASKED) x = ((i & 3) + 8 * (i >> 2) <= rel) ? x : 0.f;
                 ds[i] = x;
             }
             pack_tile<NPP>(ds, df[jt]);
@@ -190,17 +211,19 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
         advance(kt);
         __syncthreads();
     }
-    store_tile32_t<DT>(smem + w * 4096, acc, a, lane, prm.dq, prm.grad_dtype, (int64_t)bh * Nq, qw0, Nq, D);
+    // dQ_i = a e1 sum_j ds'_ij k_j  (e1 = a when the S chain carried unscaled scores)
+    const float oscale = (P == 2 && !UNIT) ? prm.a * prm.a : prm.a;
+    store_tile32_t<DT>(smem + w * 4096, acc, oscale, lane, prm.dq, prm.grad_dtype, (int64_t)bh * Nq, qw0, Nq, D);
 }
 
 // ---- dK, dV: one wave = 32 keys, NW waves per workgroup, loop over 64-query tiles -------------------------------------------
 // D <= 64 bf16 fits two waves per SIMD; the other variants hold 128..256 registers of fragments and accumulators per wave
 // and run one wave per SIMD with the accumulators in the AGPR half of the file
-template <int DP, int P, typename TIN, int NW>
+template <int DP, int P, typename TIN, int NW, bool UNIT>
 __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW == 4) ? 2 : 1) void bwd32_dkv_kernel(Quad32BwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
     constexpr int NT = 64 * NW, KT = 32 * NW;
-    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG + 512;      // Q, G (both dual use), w[64], -c w[64]
+    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG + 256;      // Q, gt (both dual use), -cw[64]
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
     static_assert(RPP <= 64 && NPASS >= 1, "staging map");
     constexpr int KS = DP / 16, DT = DP / 32;
@@ -217,27 +240,32 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
-    const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)hh * prm.gos.sh;
+    const TIN* gb = reinterpret_cast<const TIN*>(prm.gt) + (int64_t)bh * Nq * D;
     const int srow = tid / COLS, scol = tid % COLS;
 
     Frag<NP> kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = load_q_frag<TIN>(kb, prm.ks.sn, myk, Nk, 16 * ks + 8 * h, D);
+        if constexpr (UNIT) kf[ks] = load_q_frag_scaled<TIN>(kb, prm.ks.sn, myk, Nk, 16 * ks + 8 * h, D, prm.a);
+        else kf[ks] = load_q_frag<TIN>(kb, prm.ks.sn, myk, Nk, 16 * ks + 8 * h, D);
         vf[ks] = load_q_frag<TIN>(vb, prm.vs.sn, myk, Nk, 16 * ks + 8 * h, D);
     }
-    const float a = prm.a, c2 = 0.5f * prm.a * prm.a;
+    const float u0 = UNIT ? 1.0f : 1.0f / prm.a, c0 = u0 * u0;
+    f32x16 scinit;                                                        // dead when UNIT
+#pragma unroll
+    for (int i = 0; i < 16; ++i) scinit[i] = u0;
+    // rows (queries) of a score tile this lane's key may see: qlo <= query <= Nq - 1 (nothing for a key past N_k)
+    const int qlo = myk < Nk ? (causal ? myk : 0) : 0x7fffffff;
 
     u32x4 rq[NPASS], rg[NPASS];
-    float rw = 0.f, rcw = 0.f;
-    const TileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, DP, srow, scol), gload(gb, prm.gos.sn, Nq, D, DP, srow, scol);
+    float rcw = 0.f;
+    const BufTileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, srow, scol), gload(gb, D, Nq, D, srow, scol);
     auto request = [&](int it) {
         qload.load(it, rq);
         gload.load(it, rg);
         if (tid < 64) {
             const int gi = it * 64 + tid, gc = gi < Nq ? gi : Nq - 1;
-            rw = 1.0f / prm.g[(int64_t)bh * Nq + gc];
-            rcw = -prm.c[(int64_t)bh * Nq + gc] * rw;
+            rcw = -prm.cw[(int64_t)bh * Nq + gc];
         }
     };
     auto commit = [&](int stage) {
@@ -246,10 +274,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
             stage_piece<DP, TIN, 3>(smem, stage * STAGE, srow + ps * RPP, scol, rq[ps]);
             stage_piece<DP, TIN, 3>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rg[ps]);
         }
-        if (tid < 64) {
-            reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG)[tid] = rw;
-            reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG + 256)[tid] = rcw;
-        }
+        if (tid < 64) reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG)[tid] = rcw;
     };
     const int nqt = (Nq + 63) / 64;
     const int it0 = causal ? min(j0 / 64, nqt) : 0;
@@ -262,12 +287,18 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 
     auto tile = [&](int it, int stage, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int QI = stage * STAGE, GI = QI + NP * IMG, WS = GI + NP * IMG, CS = WS + 256;
+        const int QI = stage * STAGE, GI = QI + NP * IMG, CS = GI + NP * IMG;
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            f32x16 sc, u;
+            // -cw of this half's 32 queries in accumulator order: row(i) = (i&3) + 8(i>>2) + 4h
+            f32x16 ucinit;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; u[i] = 0.f; }
+            for (int ig = 0; ig < 4; ++ig) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(smem + CS + (32 * qs + 8 * ig + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ucinit[4 * ig + e] = c4[e];
+            }
+            f32x16 sc, u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag<NP> qrf, grf;
@@ -276,33 +307,29 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
                     qrf.p[p] = ld_row8<DP, 3>(smem, QI + p * IMG, 32 * qs + l31, 2 * ks + h);
                     grf.p[p] = ld_row8<DP, 3>(smem, GI + p * IMG, 32 * qs + l31, 2 * ks + h);
                 }
-                sc = mfma32_parts<NP, NP>(qrf, kf[ks], sc);                   // s[i][j]: rows = queries, col = key (lane)
-                u = mfma32_parts<NP, NP>(grf, vf[ks], u);                     // u[i][j] = G_i . v_j
+                // s[i][j] = u0 + q_i . k_j (rows = queries, column = this lane's key);  u[i][j] = gt_i . v_j - cw_i
+                sc = ks == 0 ? s_chain_head<NP, UNIT>(qrf, kf[0], scinit) : mfma32_parts<NP, NP>(qrf, kf[ks], sc);
+                u = mfma32_parts<NP, NP>(grf, vf[ks], ks == 0 ? ucinit : u);
             }
             Frag<NPP> pwf[2], dsf[2];
             {
                 float pw[16], ds[16];
+                const int lo = qlo - (it * 64 + 32 * qs) - 4 * h, hi = Nq - 1 - (it * 64 + 32 * qs) - 4 * h;
 #pragma unroll
-                for (int ig = 0; ig < 4; ++ig) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(smem + WS + (32 * qs + 8 * ig + 4 * h) * 4);
-                    const f32x4 cw4 = *reinterpret_cast<const f32x4*>(smem + CS + (32 * qs + 8 * ig + 4 * h) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * ig + e;
-                        float fv, fp;
-                        if constexpr (P == 1) { fv = fmaf(sc[i], a, 1.0f); fp = 1.0f; }
-                        else { fv = fmaf(sc[i], fmaf(sc[i], c2, a), 1.0f); fp = fmaf(sc[i], a, 1.0f); }
-                        float pwv = fv * w4[e];
-                        float dsv = fmaf(u[i], w4[e], cw4[e]) * fp;
-                        if constexpr (MASKED) {
-                            const int qi = it * 64 + 32 * qs + 8 * ig + 4 * h + e;
-                            const bool keep = qi < Nq && myk < Nk && (!causal || qi >= myk);
-                            pwv = keep ? pwv : 0.f;
-                            dsv = keep ? dsv : 0.f;
-                        }
-                        pw[i] = pwv;
-                        ds[i] = dsv;
+                for (int i = 0; i < 16; ++i) {
+                    float pwv = sc[i], dsv = u[i];
+                    if constexpr (P == 2) {
+                        pwv = fmaf(sc[i], sc[i], c0);
+                        dsv *= sc[i];
                     }
+                    if constexpr (MASKED) {
+                        const int r = (i & 3) + 8 * (i >> 2);
+                        const bool keep = r >= lo && r <= hi;
+                        pwv = keep ? pwv : 0.f;
+                        dsv = keep ? dsv : 0.f;
+                    }
+                    pw[i] = pwv;
+                    ds[i] = dsv;
                 }
                 pack_tile<NPP>(pw, pwf);
                 pack_tile<NPP>(ds, dsf);
@@ -317,8 +344,8 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
                         gtf.p[p] = ld_tr8_32<DP, 3>(smem, GI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
                         qtf.p[p] = ld_tr8_32<DP, 3>(smem, QI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
                     }
-                    dvacc[t] = mfma32_parts<NP, NPP>(gtf, pwf[s], dvacc[t]);        // dV^T[d][j] += G[i][d] P_ij w_i
-                    dkacc[t] = mfma32_parts<NP, NPP>(qtf, dsf[s], dkacc[t]);        // dK^T[m][j] += Q[i][m] dS_ij
+                    dvacc[t] = mfma32_parts<NP, NPP>(gtf, pwf[s], dvacc[t]);        // dV^T[d][j] += gt[i][d] P'_ij
+                    dkacc[t] = mfma32_parts<NP, NPP>(qtf, dsf[s], dkacc[t]);        // dK^T[m][j] += Q[i][m] dS'_ij
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -366,16 +393,19 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
         tile(it, (it - it0) & 1, std::true_type{});
         __syncthreads();
     }
-    store_tile32_t<DT>(smem + w * 4096, dkacc, a, lane, prm.dk, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
-    store_tile32_t<DT>(smem + w * 4096, dvacc, 1.0f, lane, prm.dv, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
+    // dK_j = a e1 sum_i dS'_ij q_i ;  dV_j = e2 sum_i P'_ij gt_i   (e1, e2: see the file header)
+    const float e1 = (P == 2 && !UNIT) ? prm.a : 1.0f;
+    const float e2 = (P == 1 ? 1.0f : 0.5f) * (UNIT ? 1.0f : (P == 1 ? prm.a : prm.a * prm.a));
+    store_tile32_t<DT>(smem + w * 4096, dkacc, prm.a * e1, lane, prm.dk, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
+    store_tile32_t<DT>(smem + w * 4096, dvacc, e2, lane, prm.dv, prm.grad_dtype, (int64_t)bh * Nk, jw0, Nk, D);
 }
 
-template <int DP, int P, typename TIN, int NW, int MB>
+template <int DP, int P, typename TIN, int NW, int MB, bool UNIT>
 static int launch_bwd32_dq(Quad32BwdParams prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     constexpr int st_q = 2 * 2 * NP * img_bytes<DP, 3>(), epi = NW * 4096;
     constexpr int lds_q = st_q > epi ? st_q : epi;
-    auto kq = bwd32_dq_kernel<DP, P, TIN, NW, MB>;
+    auto kq = bwd32_dq_kernel<DP, P, TIN, NW, MB, UNIT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
@@ -386,12 +416,12 @@ static int launch_bwd32_dq(Quad32BwdParams prm, hipStream_t stream) {
     hipLaunchKernelGGL(kq, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_q, stream, prm);
     return (int)hipGetLastError();
 }
-template <int DP, int P, typename TIN, int NW>
+template <int DP, int P, typename TIN, int NW, bool UNIT>
 static int launch_bwd32_dkv(Quad32BwdParams prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
-    constexpr int st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 512), epi = NW * 4096;
+    constexpr int st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 256), epi = NW * 4096;
     constexpr int lds_kv = st_kv > epi ? st_kv : epi;
-    auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW>;
+    auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW, UNIT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
@@ -402,7 +432,7 @@ static int launch_bwd32_dkv(Quad32BwdParams prm, hipStream_t stream) {
     hipLaunchKernelGGL(kkv, dim3(prm.nblk * prm.BH), dim3(64 * NW), lds_kv, stream, prm);
     return (int)hipGetLastError();
 }
-template <int DP, int P, typename TIN>
+template <int DP, int P, typename TIN, bool UNIT>
 static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     static const int vq = [] { const char* e = getenv("FASTMAX_BWD32_DQ"); return e ? atoi(e) : -1; }();
@@ -410,20 +440,25 @@ static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
     int rc;
     // dQ variants: 0 = 4 waves, two workgroups per CU (256 registers); 1 = 4 waves, one workgroup per CU (whole file);
     // 2 = 8 waves, one workgroup per CU
-    // measured (C4, bf16 D = 128): 2.14 / 1.67 / 1.81 ms forward+backward for variants 0 / 1 / 2 -- the 256-register cap
-    // spills 276 bytes per lane into the tile loop; D = 64: 5.75 / 5.99 / 5.85
     constexpr int DEF_Q = (DP == 64 && NP == 2) ? 2 : (DP == 64 ? 0 : 1);
     const int q = vq >= 0 ? vq : DEF_Q;
-    if (q == 2) rc = launch_bwd32_dq<DP, P, TIN, 8, 1>(prm, stream);
-    else if (q == 1) rc = launch_bwd32_dq<DP, P, TIN, 4, 1>(prm, stream);
-    else rc = launch_bwd32_dq<DP, P, TIN, 4, 2>(prm, stream);
+    if (q == 2) rc = launch_bwd32_dq<DP, P, TIN, 8, 1, UNIT>(prm, stream);
+    else if (q == 1) rc = launch_bwd32_dq<DP, P, TIN, 4, 1, UNIT>(prm, stream);
+    else rc = launch_bwd32_dq<DP, P, TIN, 4, 2, UNIT>(prm, stream);
     if (rc) return rc;
     const int nwkv = vkv ? vkv : ((DP == 64 && NP == 2) ? 8 : 4);
-    return nwkv == 8 ? launch_bwd32_dkv<DP, P, TIN, 8>(prm, stream) : launch_bwd32_dkv<DP, P, TIN, 4>(prm, stream);
+    return nwkv == 8 ? launch_bwd32_dkv<DP, P, TIN, 8, UNIT>(prm, stream) : launch_bwd32_dkv<DP, P, TIN, 4, UNIT>(prm, stream);
+}
+static bool is_pow2(float a) { int e; return a > 0.f && frexpf(a, &e) == 0.5f; }
+template <int DP, int P, typename TIN>
+static int launch_bwd32_u(const Quad32BwdParams& prm, hipStream_t stream) {
+    // split (fp32 / fp16) operands are scaled in fp32 before the split; bf16 rows only by a power of two (exact)
+    if constexpr (InTraits<TIN>::NP == 2) return launch_bwd32_n<DP, P, TIN, true>(prm, stream);
+    else return is_pow2(prm.a) ? launch_bwd32_n<DP, P, TIN, true>(prm, stream) : launch_bwd32_n<DP, P, TIN, false>(prm, stream);
 }
 template <int P, typename TIN>
 static int launch_bwd32_d(const Quad32BwdParams& prm, hipStream_t stream) {
-    return prm.D <= 64 ? launch_bwd32_n<64, P, TIN>(prm, stream) : launch_bwd32_n<128, P, TIN>(prm, stream);
+    return prm.D <= 64 ? launch_bwd32_u<64, P, TIN>(prm, stream) : launch_bwd32_u<128, P, TIN>(prm, stream);
 }
 template <typename TIN>
 static int launch_bwd32_p(const Quad32BwdParams& prm, int p, hipStream_t stream) {
@@ -436,10 +471,18 @@ bool quad32_bwd_supported(const fastmax_problem& p) {
     const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
     return (p.D % epl) == 0 && p.D <= 128 && p.Nq >= 256 && p.Nk >= 256 && (int64_t)p.B * p.H * ((max(p.Nq, p.Nk) + 127) / 128) <= 0x7fffffff;
 }
+// every streamed (b,h) slab fits the 31-bit buffer offsets of BufTileLoader
+bool quad32_bwd_layout_ok(const BwdArgs& a) {
+    const int eb = a.prob.in_dtype == FASTMAX_F32 ? 4 : 2;
+    return quad32_span_ok(a.qs.sn, a.prob.Nq, a.prob.D, eb) && quad32_span_ok(a.ks.sn, a.prob.Nk, a.prob.D, eb) &&
+           quad32_span_ok(a.vs.sn, a.prob.Nk, a.prob.D, eb) && quad32_span_ok(a.prob.D, a.prob.Nq, a.prob.D, eb);
+}
 
-// c (B,H,Nq) = rowsum(G o) must already be in a.workspace (bwd_prep_kernel of fastmax_quad_mfma_bwd.hip)
+// the prep pass (bwd_prep_kernel of fastmax_quad_mfma_bwd.hip, gt mode) has left cw (B,H,Nq) at the head of a.workspace
+// and gt = w G (B,H,Nq,D) at quad32_bwd_gt_offset
 int launch_bwd_quad32_main(const BwdArgs& a) {
-    Quad32BwdParams prm{a.q, a.k, a.v, a.grad_o, a.g, reinterpret_cast<const float*>(a.workspace), a.qs, a.ks, a.vs, a.gos,
+    Quad32BwdParams prm{a.q, a.k, a.v, reinterpret_cast<const char*>(a.workspace) + quad32_bwd_gt_offset(a.prob),
+                        reinterpret_cast<const float*>(a.workspace), a.qs, a.ks, a.vs,
                         a.dq, a.dk, a.dv, a.prob.H, a.prob.B * a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal,
                         a.prob.in_dtype, 0, a.prob.a};
     switch (a.prob.in_dtype) {

@@ -9,11 +9,21 @@
 //     tile t and tile t+2 is requested immediately (one barrier per tile, loads one full tile ahead)
 //   * S^T = K Q^T keeps the key on the accumulator row, so P = f(a S) in registers is already the B operand of
 //     O^T += V^T P^T; V^T fragments come from ds_read_b64_tr_b16 with the matching key order
-//   * f is two fused multiply-adds per element: 1 + s (a + s a^2/2)
+//   * f costs ONE vector instruction per element (round 3).  With u = 1/a + q.k the polynomial is a perfect-square form:
+//         p = 1:  1 + a s         = a u
+//         p = 2:  1 + a s + (a s)^2 / 2 = (a^2 / 2) (u^2 + 1/a^2)
+//     u comes straight out of the S^T chain, whose accumulator starts at the constant 1/a instead of 0 (when a is a
+//     power of two, or the operands are split fp32 / fp16 values, Q is scaled by a on load and the constant is the inline
+//     1.0); the common factor (a or a^2/2) cancels in o = F / g and is applied to the stored g only.  Per score element
+//     the tile loop issues one v_fma (u u + c), one v_add (row sum) and half a v_cvt_pk: 2.5 vector instructions against
+//     5.2 before, none of them packed-f32 (v_pk_* beside MFMAs costs 3-4x its issue slot on gfx950).
+//   * K / V tiles ride on buffer descriptors whose record count is the head's own byte range: rows past N_k and padded
+//     head columns read as zero in hardware, a tile request is four loads and four integer adds
 // 32x32x16 layouts (A: row = lane&31, k = 8(lane>>5)+j; B: col = lane&31, same k; C: col = lane&31,
 // row(i) = (i&3) + 8(i>>2) + 4(lane>>5)).
 #include "fastmax_mfma32_common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -26,6 +36,8 @@ __device__ unsigned long long* g_q32_stamps = nullptr;
 #else
 #define Q32_STAMP(var) do { } while (0)
 #endif
+
+#define QUAD32_DEFAULT_SCHED(DP) ((DP) == 128 ? 1 : 0)
 
 struct Quad32Params {
     const void *q, *k, *v;
@@ -43,7 +55,9 @@ template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks
 }
 
 // 1-D grid of nqt * BH workgroups; block = 64 NW threads; dynamic LDS = max(2 stages of K,V images, NW * 4 KiB)
-template <int DP, int P, typename TIN, int NPP, int NW, int ABL = 0>
+// UNIT: Q is scaled by a on load and the score chain starts at the inline constant 1.0 (u = 1 + a q.k); otherwise the
+// chain starts at a register tile holding 1/a (u = 1/a + q.k) -- single-part operands whose scale is not a power of two
+template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED>
 __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) void fwd_quad32_kernel(Quad32Params prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int NT = 64 * NW, QT = 32 * NW;
@@ -81,10 +95,13 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
 
     Frag<NP> qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+    for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (UNIT) qf[ks] = load_q_frag_scaled<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D, prm.a);
+        else qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+    }
 
     u32x4 rk[NPASS], rv[NPASS];
-    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, DP, srow, scol), vload(vb, prm.vs.sn, Nk, D, DP, srow, scol);
+    const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
     auto request = [&](int kt) {
         kload.load(kt, rk);
         vload.load(kt, rv);
@@ -104,26 +121,30 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
     float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const float a = prm.a, c2 = 0.5f * prm.a * prm.a;
+    // u = u0 + (scaled) q.k out of the score chain; f = fscale * (p == 1 ? u : u u + c0)
+    const float u0 = UNIT ? 1.0f : 1.0f / prm.a, c0 = u0 * u0;
+    const float fscale = (P == 1 ? 1.0f : 0.5f) * (UNIT ? 1.0f : (P == 1 ? prm.a : prm.a * prm.a));
+    f32x16 cinit;                                                     // dead when UNIT
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = u0;
 #ifdef FASTMAX_QUAD32_STAMPS
     unsigned long long q32_t = __builtin_amdgcn_s_memtime(), st_qk = 0, st_poly = 0, st_pv = 0, st_adv = 0, st_bar = 0, st_tiles = 0, st_wait = 0, st_commit = 0;
     const unsigned long long q32_t0 = q32_t;
 #endif
 
+    const int klim = causal ? min(myq, Nk - 1) : Nk - 1;
     // f(a s) of one S^T tile (32 keys x 32 queries) -> the two B fragments (16 keys each) of the P^T operand
     auto poly = [&](const f32x16& sc, int key0, auto masked_tag, Frag<NPP> (&pf)[2]) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         float pv[16];
+        // masked tiles: element i of this lane is key key0 + 4h + (i&3) + 8(i>>2); it counts while key <= klim
+        // (klim = last key this lane's query may see): one compare against a compile-time row offset per element
+        const int rel = klim - key0 - 4 * h;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float x;
-            if constexpr (P == 1) x = fmaf(sc[i], a, 1.0f);
-            else x = fmaf(sc[i], fmaf(sc[i], c2, a), 1.0f);
-            if constexpr (MASKED) {
-                const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const bool keep = key < Nk && (!causal || key <= myq);
-                x = keep ? x : 0.f;
-            }
+            float x = sc[i];
+            if constexpr (P == 2) x = fmaf(x, x, c0);
+            if constexpr (MASKED) x = ((i & 3) + 8 * (i >> 2) <= rel) ? x : 0.f;
             pv[i] = x;
             gsum[i & 3] += x;
         }
@@ -152,13 +173,9 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int QKM = KS * (NP == 2 ? 3 : 1);                   // MFMAs of one S chain
         constexpr int PVM = 2 * DT * (1 + (NP == 2) + (NPP == 2));    // MFMAs of one key half of O^T += V^T P^T
-        constexpr int VPOLY = (P == 2 ? 16 : 8) + 8 + (NPP == 2 ? 40 : 8) + (MASKED ? 48 : 0);   // VALU of one poly()
+        constexpr int VPOLY = (P == 2 ? 16 : 0) + 16 + (NPP == 2 ? 40 : 8) + (MASKED ? 32 : 0);   // VALU of one poly()
         const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
         f32x16 sc[2];
-        if constexpr (ABL != 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[0][i] = oacc[0][i]; sc[1][i] = oacc[DT - 1][i]; }
-        }
         Frag<NP> kf[2][KS];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -167,16 +184,6 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
 #pragma unroll
                 for (int p = 0; p < NP; ++p) kf[jt][ks].p[p] = ld_row8<DP, 1>(smem, KI + p * KIMG, 32 * jt + l31, 2 * ks + h);
         Frag<NP> vf[2][2][DT];
-        if constexpr (ABL != 0) {
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = qf[dt].p[p];
-        }
         auto vread = [&](int jt) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -186,27 +193,22 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
                     for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
         };
         auto qk = [&](int jt) {
+            if constexpr (UNIT) {
+                sc[jt] = mfma32_parts_c1<NP, NP>(kf[jt][0], qf[0]);
+            } else {
+                sc[jt] = mfma32_parts<NP, NP>(kf[jt][0], qf[0], cinit);
+            }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sc[jt][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) sc[jt] = mfma32_parts<NP, NP>(kf[jt][ks], qf[ks], sc[jt]);
+            for (int ks = 1; ks < KS; ++ks) sc[jt] = mfma32_parts<NP, NP>(kf[jt][ks], qf[ks], sc[jt]);
         };
         Frag<NPP> pf[2][2];
-        if constexpr (ABL != 0) {
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int p = 0; p < NPP; ++p) pf[jt][s].p[p] = qf[s].p[0];
-        }
         auto pv = [&](int jt) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32_parts<NP, NPP>(vf[jt][s][dt], pf[jt][s], oacc[dt]);
         };
-        if constexpr (DP == 128) {
+        if constexpr (SCHED == 1) {
             // A
             qk(0);
             vread(0);
@@ -233,21 +235,21 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
             // D
             pv(1);
         } else {
-            // D <= 64 (measured): leaving the two S chains to the compiler and walling only the polynomial off, with the
-            // V^T fragments requested ahead of it, is 4 % faster than the grouped issue and needs no spill
-            if (!(ABL & 16)) { qk(0); qk(1); }
+            // both S chains first, then per half: V^T fragments requested, polynomial walled off, O^T product
+            qk(0);
+            qk(1);
 #ifdef FASTMAX_QUAD32_STAMPS
             __builtin_amdgcn_sched_barrier(0);
 #endif
             Q32_STAMP(st_qk);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                if (!(ABL & 8)) vread(jt);
+                vread(jt);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(ABL & 4)) poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
+                poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
                 __builtin_amdgcn_sched_barrier(0);
                 Q32_STAMP(st_poly);
-                if (!(ABL & 32)) pv(jt);
+                pv(jt);
 #ifdef FASTMAX_QUAD32_STAMPS
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -263,12 +265,12 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // diagnostic: the wait for tile kt+1's loads on its own
             Q32_STAMP(st_wait);
 #endif
-            if (!(ABL & 1)) commit((kt & 1) ^ 1);
+            commit((kt & 1) ^ 1);
 #ifdef FASTMAX_QUAD32_STAMPS
             __builtin_amdgcn_sched_barrier(0);
             Q32_STAMP(st_commit);
 #endif
-            if (kt + 2 < nkt && !(ABL & 2)) request(kt + 2);
+            if (kt + 2 < nkt) request(kt + 2);
         }
     };
     // per wave: tiles [0, n_plain) lie wholly below the diagonal and inside N_k, [n_plain, n_act) need the masks,
@@ -314,19 +316,20 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
 #endif
     float gs = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
     gs += __shfl_xor(gs, 32, 64);
+    gs *= fscale;
     // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
     const float gval = causal ? gs : gs - (float)Nk + prm.g0;
     if (myq < Nq && prm.g && h == 0) prm.g[(int64_t)bh * Nq + myq] = gval;
-    const float ginv = 1.0f / gval;
+    const float ginv = fscale / gval;
     store_tile32_t<DT>(smem + w * 4096, oacc, ginv, lane, prm.o, prm.out_dtype, (int64_t)bh * Nq, qw0, Nq, D);
 }
 
-template <int DP, int P, typename TIN, int NPP, int NW, int ABL = 0>
+template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED>
 static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     constexpr int stages = 2 * NP * (img_bytes<DP, 1>() + img_bytes<DP, 2>()), epi = NW * 4096;
     constexpr int lds = stages > epi ? stages : epi;
-    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW, ABL>;
+    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW, UNIT, SCHED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -337,37 +340,32 @@ static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(prm.nqt * prm.BH), dim3(64 * NW), lds, stream, prm);
     return (int)hipGetLastError();
 }
-template <int DP, int P, typename TIN, int NPP>
+template <int DP, int P, typename TIN, int NPP, bool UNIT>
 static int launch_quad32_n(const Quad32Params& prm, hipStream_t stream) {
     static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_NW"); return e ? atoi(e) : 0; }();
+    static const int sched = [] { const char* e = getenv("FASTMAX_QUAD32_SCHED"); return e ? atoi(e) : -1; }();
     const int nw = forced ? forced : ((DP == 64 && InTraits<TIN>::NP == 1) ? 4 : 8);
-#ifdef FASTMAX_QUAD32_ABLATION
-    if constexpr (DP == 64 && P == 2 && InTraits<TIN>::NP == 1 && NPP == 1) {
-        static const int abl = [] { const char* e = getenv("FASTMAX_QUAD32_ABL"); return e ? atoi(e) : 0; }();
-        switch (abl) {
-            case 1: return launch_quad32_w<DP, P, TIN, NPP, 4, 1>(prm, stream);
-            case 3: return launch_quad32_w<DP, P, TIN, NPP, 4, 3>(prm, stream);
-            case 4: return launch_quad32_w<DP, P, TIN, NPP, 4, 4>(prm, stream);
-            case 8: return launch_quad32_w<DP, P, TIN, NPP, 4, 8>(prm, stream);
-            case 16: return launch_quad32_w<DP, P, TIN, NPP, 4, 16>(prm, stream);
-            case 24: return launch_quad32_w<DP, P, TIN, NPP, 4, 24>(prm, stream);
-            case 28: return launch_quad32_w<DP, P, TIN, NPP, 4, 28>(prm, stream);
-            case 31: return launch_quad32_w<DP, P, TIN, NPP, 4, 31>(prm, stream);
-            case 35: return launch_quad32_w<DP, P, TIN, NPP, 4, 35>(prm, stream);
-            case 60: return launch_quad32_w<DP, P, TIN, NPP, 4, 60>(prm, stream);
-            case 63: return launch_quad32_w<DP, P, TIN, NPP, 4, 63>(prm, stream);
-            default: break;
-        }
-    }
-#endif
-    return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4>(prm, stream);
+    // issue order of a tile (see the kernel): 1 = polynomial of one key half in the shadow of the other half's matrix
+    // instructions (grouped issue), 0 = compiler order with the polynomial walled off
+    constexpr int DEF_SCHED = QUAD32_DEFAULT_SCHED(DP);
+    const int sc = sched >= 0 ? sched : DEF_SCHED;
+    if (sc == 1)
+        return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8, UNIT, 1>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 1>(prm, stream);
+    return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8, UNIT, 0>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 0>(prm, stream);
+}
+// a = 2^e exactly: scaling single-part (bf16) query fragments by it loses nothing
+static bool is_pow2(float a) { int e; return a > 0.f && frexpf(a, &e) == 0.5f; }
+template <int DP, int P, typename TIN, int NPP>
+static int launch_quad32_u(const Quad32Params& prm, hipStream_t stream) {
+    if constexpr (InTraits<TIN>::NP == 2) return launch_quad32_n<DP, P, TIN, NPP, true>(prm, stream);
+    else return is_pow2(prm.a) ? launch_quad32_n<DP, P, TIN, NPP, true>(prm, stream) : launch_quad32_n<DP, P, TIN, NPP, false>(prm, stream);
 }
 template <int DP, int P, typename TIN>
 static int launch_quad32_t(const Quad32Params& prm, hipStream_t stream) {
     if constexpr (InTraits<TIN>::NP == 1) {
-        if (prm.out_dtype != FASTMAX_F32) return launch_quad32_n<DP, P, TIN, 1>(prm, stream);
+        if (prm.out_dtype != FASTMAX_F32) return launch_quad32_u<DP, P, TIN, 1>(prm, stream);
     }
-    return launch_quad32_n<DP, P, TIN, 2>(prm, stream);
+    return launch_quad32_u<DP, P, TIN, 2>(prm, stream);
 }
 template <int P, typename TIN>
 static int launch_quad32_d(const Quad32Params& prm, hipStream_t stream) {
@@ -391,6 +389,8 @@ bool quad32_supported(const fastmax_problem& p) {
 
 int launch_fwd_quad32(const FwdArgs& a) {
     if (!quad32_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    const int eb = a.prob.in_dtype == FASTMAX_F32 ? 4 : 2;
+    if (!quad32_span_ok(a.ks.sn, a.prob.Nk, a.prob.D, eb) || !quad32_span_ok(a.vs.sn, a.prob.Nk, a.prob.D, eb)) return launch_fwd_quad_mfma(a);
     Quad32Params prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, a.prob.H, a.prob.B * a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D,
                      a.prob.causal, a.prob.out_dtype, 0, a.prob.a, a.prob.g0};
     switch (a.prob.in_dtype) {

@@ -20,7 +20,26 @@ struct QuadBwdParams {
     float* c;                       // workspace (B,H,Nq)
     int H, Nq, Nk, D, causal, grad_dtype, o_dtype;
     float a;
+    void* gt = nullptr;             // 32x32-tile kernels: prep also writes gt_i = w_i G_i (B,H,Nq,D, input dtype) and c_i w_i
 };
+
+// w_i G_i for the 32x32-tile kernels (fastmax_quad32_bwd.hip): with the row factor w_i = 1/g_i folded into the streamed
+// operand, (u_ij - c_i) w_i = gt_i.v_j - c_i w_i leaves the score chain directly and dV_j = sum_i P_ij gt_i
+template <typename TIN, int EPL>
+__device__ __forceinline__ void store_scaled_piece(void* gt, int64_t elem, const float (&x)[EPL], float w) {
+    if constexpr (sizeof(TIN) == 4) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(gt) + elem) = f32x4{x[0] * w, x[1] * w, x[2] * w, x[3] * w};
+    } else if constexpr (InTraits<TIN>::NP == 1) {
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(gt) + elem) =
+            cat4(to_bf16x4(f32x4{x[0] * w, x[1] * w, x[2] * w, x[3] * w}), to_bf16x4(f32x4{x[4] * w, x[5] * w, x[6] * w, x[7] * w}));
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(x[e] * w);
+        *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(gt) + elem) = o;
+    }
+}
 
 __device__ __forceinline__ float load_elem(const void* base, int dtype, int64_t idx) {
     if (dtype == FASTMAX_F32) return reinterpret_cast<const float*>(base)[idx];
@@ -40,6 +59,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(QuadBwdParams prm) {
     float s = 0.f;
     for (int d = lane; d < prm.D; d += 64) s = fmaf(to_float(grow[d]), load_elem(prm.o, prm.o_dtype, ob + d), s);
     s = wave_sum(s);
+    if (prm.gt) {
+        const float w = 1.0f / prm.g[(int64_t)bh * prm.Nq + i];
+        TIN* dst = reinterpret_cast<TIN*>(prm.gt) + ((int64_t)bh * prm.Nq + i) * prm.D;
+        for (int d = lane; d < prm.D; d += 64) dst[d] = from_float<TIN>(to_float(grow[d]) * w);
+        s *= w;
+    }
     if (lane == 0) prm.c[(int64_t)bh * prm.Nq + i] = s;
 }
 
@@ -76,6 +101,11 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(QuadBwdParams prm) {
     for (int e = 0; e < EPL; ++e) s = fmaf(x[e], y[e], s);
 #pragma unroll
     for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (prm.gt) {
+        const float w = 1.0f / prm.g[(int64_t)bh * prm.Nq + ic];
+        if (live) store_scaled_piece<TIN, EPL>(prm.gt, ((int64_t)bh * prm.Nq + i) * prm.D + sub * EPL, x, w);
+        s *= w;
+    }
     if (live && sub == 0) prm.c[(int64_t)bh * prm.Nq + i] = s;
 }
 
@@ -410,10 +440,12 @@ bool quad_mfma_bwd_supported(const fastmax_problem& p) {
 // 32x32-tile kernels (fastmax_quad32_bwd.hip) behind the same prep launch
 int launch_bwd_quad32(const BwdArgs& a) {
     if (!quad32_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
-    if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;
+    if (!quad32_bwd_layout_ok(a)) return launch_bwd_quad_mfma(a);
+    if (a.workspace_bytes < bwd_quadratic_workspace(a.prob) || !a.workspace) return FASTMAX_E_WORKSPACE;
     QuadBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                       reinterpret_cast<float*>(a.workspace), a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal,
                       a.prob.in_dtype, a.prob.out_dtype, a.prob.a};
+    prm.gt = reinterpret_cast<char*>(a.workspace) + quad32_bwd_gt_offset(a.prob);
     switch (a.prob.in_dtype) {
         case FASTMAX_F32: launch_prep<float>(prm, a.prob.B * a.prob.H, a.stream); break;
         case FASTMAX_BF16: launch_prep<bf16_t>(prm, a.prob.B * a.prob.H, a.stream); break;

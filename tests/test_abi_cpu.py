@@ -52,7 +52,8 @@ def test_problem_validation_without_gpu(lib):
     assert lib.fastmax_hip_select_path(ctypes.byref(big_d)) == -2
     # null pointers are rejected before anything is launched
     assert lib.fastmax_hip_forward(ctypes.byref(ok), None, None, None, None, None, None, None, None, None, 0, None) == -6
-    assert lib.fastmax_hip_backward_workspace(ctypes.byref(ok)) == 4 * 2 * 4 * 256
+    # c w (B,H,Nq) floats, then the 32x32-tile kernels' w G copy (B,H,Nq,D) in the input dtype
+    assert lib.fastmax_hip_backward_workspace(ctypes.byref(ok)) == 4 * 2 * 4 * 256 + 4 * 2 * 4 * 256 * 64
 
 
 def test_reference_import_paths_and_signatures():

@@ -17,7 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
 # per-source flags.  The p=2 tile kernels interleave their per-score vector work with MFMAs: packed-f32 instructions
 # (v_pk_fma_f32 / v_pk_add_f32, which the SLP vectoriser forms from adjacent scalar operations) cost 3-4x their issue slot
 # beside matrix instructions on gfx950, so those files are built without it.
-FILE_FLAGS = {"fastmax_quad32_mfma.hip": ["-fno-slp-vectorize"], "fastmax_quad32_bwd.hip": ["-fno-slp-vectorize"]}
+# The backward kernels that take the whole register file (one wave per SIMD) would otherwise get their MFMAs selected in the
+# accumulator-file form, which moves every score tile between the two halves of the file (v_accvgpr_read / _write) on its way
+# to and from the vector ALU: -amdgpu-mfma-vgpr-form keeps matrix results in the VGPRs the vector instructions read.
+FILE_FLAGS = {"fastmax_quad32_mfma.hip": ["-fno-slp-vectorize"],
+              "fastmax_quad32_bwd.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():

@@ -38,6 +38,24 @@ __device__ __forceinline__ f32x16 mfma32_parts(const Frag<NA>& a, const Frag<NB>
     return c;
 }
 
+// Accumulate into a tile that lives in the ACCUMULATOR half of the register file (AGPRs).  The one-wave-per-SIMD backward
+// kernels at D = 128 keep their output accumulators (64 - 128 registers that only matrix instructions touch) there, while the
+// score chains -- whose results the vector ALU reads -- are compiled in the VGPR form (-amdgpu-mfma-vgpr-form): the compiler
+// selects one form for every MFMA of a kernel, so the accumulator-file ones are written out.  `s_nop 1`: a vector-ALU write of
+// an operand just before the statement (the packed score tile).  Chains into the same accumulator need no wait states; any
+// other reader must come after acc_fence().
+__device__ __forceinline__ void mfma32_acc(f32x16& acc, const bf16x8 a, const bf16x8 b) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int NA, int NB>
+__device__ __forceinline__ void mfma32_parts_acc(f32x16& acc, const Frag<NA>& a, const Frag<NB>& b) {
+    mfma32_acc(acc, a.p[0], b.p[0]);
+    if constexpr (NA == 2) mfma32_acc(acc, a.p[1], b.p[0]);
+    if constexpr (NB == 2) mfma32_acc(acc, a.p[0], b.p[1]);
+}
+// 16 wait states between the last matrix instruction into `acc` and whatever the compiler does with it next
+__device__ __forceinline__ void acc_fence(f32x16& acc) { asm volatile("s_nop 15" : "+a"(acc)); }
+
 // A operand of the 32x32x16 MFMA from a row-major image, transposed: lane (d = lane&31, h = lane>>5) receives
 // rows row0 + 4h + {0..3} and row0 + 8 + 4h + {0..3} of image column col0 + d  (= the key order of the accumulator
 // registers 8s..8s+7 of an S^T tile).

@@ -82,10 +82,19 @@ template <int DP, int P, typename TIN, int NW, int MB, bool UNIT>
 __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
     constexpr int NT = 64 * NW, QT = 32 * NW;
-    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG;          // K (dual use) then V (row reads)
+    // K is read by rows (S chain) and transposed (dQ product), V by rows.  D <= 64: K in one dual-use XOR image.  D = 128: 48
+    // fragment reads per tile would each need their own XOR-ed address (~100 integer instructions per tile), so K gets a
+    // padded row image AND a padded transposed-read image: every fragment address is one lane constant + an immediate
+    constexpr bool DUAL = DP == 128 && NP == 1;                            // two-part operands: the images would not fit
+    constexpr int SWR = DUAL ? 1 : 3, SWT = DUAL ? 2 : 3;
+    constexpr int IMG = img_bytes<DP, SWR>(), IMGT = DUAL ? img_bytes<DP, SWT>() : 0;
+    constexpr int KTO = 2 * NP * IMG, STAGE = 2 * NP * IMG + NP * IMGT;     // K rows, V rows[, K transposed-read copy]
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
     static_assert(RPP <= 64 && NPASS >= 1, "staging map");
     constexpr int KS = DP / 16, DT = DP / 32;
+    // the whole-file kernels at D = 128 keep the output accumulators in the AGPR half (mfma32_acc): the VGPRs are then free for
+    // fragment reads in flight, without which every MFMA of a lone wave waits a full LDS round trip
+    constexpr bool ACC_A = DP == 128 && MB == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,8 +137,9 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
     auto commit = [&](int stage) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN, 3>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
-            stage_piece<DP, TIN, 3>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rv[ps]);
+            stage_piece<DP, TIN, SWR>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
+            stage_piece<DP, TIN, SWR>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rv[ps]);
+            if constexpr (DUAL) stage_piece<DP, TIN, SWT>(smem, stage * STAGE + KTO, srow + ps * RPP, scol, rk[ps]);
         }
     };
     const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
@@ -142,22 +152,27 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
 
     auto tile = [&](int kt, int stage, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int KI = stage * STAGE, VI = KI + NP * IMG, k0 = kt * 64;
+        const int KI = stage * STAGE, VI = KI + NP * IMG, KT = DUAL ? KI + KTO : KI, k0 = kt * 64;
+        constexpr int TIMG = DUAL ? IMGT : IMG;
         Frag<NPP> df[2][2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
+            // all row fragments of this key half are requested before the two chains start: a read issued next to its MFMA
+            // costs a full LDS round trip per matrix instruction when the wave is alone on its SIMD
+            Frag<NP> kfr[KS], vfr[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    vfr[ks].p[p] = ld_row8<DP, SWR>(smem, VI + p * IMG, 32 * jt + l31, 2 * ks + h);
+                    if constexpr (P == 2) kfr[ks].p[p] = ld_row8<DP, SWR>(smem, KI + p * IMG, 32 * jt + l31, 2 * ks + h);
+                }
             f32x16 sc, u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag<NP> kf, vf;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    vf.p[p] = ld_row8<DP, 3>(smem, VI + p * IMG, 32 * jt + l31, 2 * ks + h);
-                    if constexpr (P == 2) kf.p[p] = ld_row8<DP, 3>(smem, KI + p * IMG, 32 * jt + l31, 2 * ks + h);
-                }
                 // u[j][i] = v_j . gt_i - cw_i ;  s[j][i] = u0 + k_j . q_i
-                u = mfma32_parts<NP, NP>(vf, gf[ks], ks == 0 ? ucinit : u);
-                if constexpr (P == 2) sc = ks == 0 ? s_chain_head<NP, UNIT>(kf, qf[0], scinit) : mfma32_parts<NP, NP>(kf, qf[ks], sc);
+                u = mfma32_parts<NP, NP>(vfr[ks], gf[ks], ks == 0 ? ucinit : u);
+                if constexpr (P == 2) sc = ks == 0 ? s_chain_head<NP, UNIT>(kfr[0], qf[0], scinit) : mfma32_parts<NP, NP>(kfr[ks], qf[ks], sc);
             }
             float ds[16];
             const int rel = klim - (k0 + 32 * jt) - 4 * h;
@@ -171,16 +186,22 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
             pack_tile<NPP>(ds, df[jt]);
         }
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < 2; ++jt) {
+            Frag<NP> ktf[2][DT];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int mt = 0; mt < DT; ++mt) {
-                    Frag<NP> ktf;
+                for (int mt = 0; mt < DT; ++mt)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) ktf.p[p] = ld_tr8_32<DP, 3>(smem, KI + p * IMG, 32 * jt + 16 * s, 32 * mt, lane);
-                    acc[mt] = mfma32_parts<NP, NPP>(ktf, df[jt][s], acc[mt]);    // dQ^T[m][i] += K[j][m] dS[j][i]
+                    for (int p = 0; p < NP; ++p) ktf[s][mt].p[p] = ld_tr8_32<DP, SWT>(smem, KT + p * TIMG, 32 * jt + 16 * s, 32 * mt, lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {                                    // dQ^T[m][i] += K[j][m] dS[j][i]
+                    if constexpr (ACC_A) mfma32_parts_acc<NP, NPP>(acc[mt], ktf[s][mt], df[jt][s]);
+                    else acc[mt] = mfma32_parts<NP, NPP>(ktf[s][mt], df[jt][s], acc[mt]);
                 }
+        }
     };
     auto advance = [&](int kt) {
         if (kt + 1 < nkt) {
@@ -211,6 +232,10 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
         advance(kt);
         __syncthreads();
     }
+    if constexpr (ACC_A) {
+#pragma unroll
+        for (int mt = 0; mt < DT; ++mt) acc_fence(acc[mt]);
+    }
     // dQ_i = a e1 sum_j ds'_ij k_j  (e1 = a when the S chain carried unscaled scores)
     const float oscale = (P == 2 && !UNIT) ? prm.a * prm.a : prm.a;
     store_tile32_t<DT>(smem + w * 4096, acc, oscale, lane, prm.dq, prm.grad_dtype, (int64_t)bh * Nq, qw0, Nq, D);
@@ -223,10 +248,16 @@ template <int DP, int P, typename TIN, int NW, bool UNIT>
 __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW == 4) ? 2 : 1) void bwd32_dkv_kernel(Quad32BwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, NPP = NP;
     constexpr int NT = 64 * NW, KT = 32 * NW;
-    constexpr int IMG = img_bytes<DP, 3>(), STAGE = 2 * NP * IMG + 256;      // Q, gt (both dual use), -cw[64]
+    // Q and gt are both read by rows (S, U chains) and transposed (dK, dV products): one dual-use XOR image each at D <= 64,
+    // a padded row image + a padded transposed-read image each at D = 128 (see bwd32_dq_kernel)
+    constexpr bool DUAL = DP == 128 && NP == 1;                            // two-part operands: the images would not fit
+    constexpr int SWR = DUAL ? 1 : 3, SWT = DUAL ? 2 : 3;
+    constexpr int IMG = img_bytes<DP, SWR>(), IMGT = DUAL ? img_bytes<DP, SWT>() : 0;
+    constexpr int TRO = 2 * NP * IMG, CWO = TRO + 2 * NP * IMGT, STAGE = CWO + 256;   // Q rows, gt rows[, Q tr, gt tr], -cw[64]
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
     static_assert(RPP <= 64 && NPASS >= 1, "staging map");
     constexpr int KS = DP / 16, DT = DP / 32;
+    constexpr bool ACC_A = DP == 128 && NW == 4;                          // accumulators in the AGPR half (see bwd32_dq_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,10 +302,14 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
     auto commit = [&](int stage) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            stage_piece<DP, TIN, 3>(smem, stage * STAGE, srow + ps * RPP, scol, rq[ps]);
-            stage_piece<DP, TIN, 3>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rg[ps]);
+            stage_piece<DP, TIN, SWR>(smem, stage * STAGE, srow + ps * RPP, scol, rq[ps]);
+            stage_piece<DP, TIN, SWR>(smem, stage * STAGE + NP * IMG, srow + ps * RPP, scol, rg[ps]);
+            if constexpr (DUAL) {
+                stage_piece<DP, TIN, SWT>(smem, stage * STAGE + TRO, srow + ps * RPP, scol, rq[ps]);
+                stage_piece<DP, TIN, SWT>(smem, stage * STAGE + TRO + NP * IMGT, srow + ps * RPP, scol, rg[ps]);
+            }
         }
-        if (tid < 64) reinterpret_cast<float*>(smem + stage * STAGE + 2 * NP * IMG)[tid] = rcw;
+        if (tid < 64) reinterpret_cast<float*>(smem + stage * STAGE + CWO)[tid] = rcw;
     };
     const int nqt = (Nq + 63) / 64;
     const int it0 = causal ? min(j0 / 64, nqt) : 0;
@@ -287,7 +322,9 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 
     auto tile = [&](int it, int stage, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int QI = stage * STAGE, GI = QI + NP * IMG, CS = GI + NP * IMG;
+        const int QI = stage * STAGE, GI = QI + NP * IMG, CS = QI + CWO;
+        const int QTI = DUAL ? QI + TRO : QI, GTI = DUAL ? QTI + NP * IMGT : GI;
+        constexpr int TIMG = DUAL ? IMGT : IMG;
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             // -cw of this half's 32 queries in accumulator order: row(i) = (i&3) + 8(i>>2) + 4h
@@ -298,18 +335,20 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ucinit[4 * ig + e] = c4[e];
             }
+            Frag<NP> qrf[KS], grf[KS];                                  // requested up front (see bwd32_dq_kernel)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    qrf[ks].p[p] = ld_row8<DP, SWR>(smem, QI + p * IMG, 32 * qs + l31, 2 * ks + h);
+                    grf[ks].p[p] = ld_row8<DP, SWR>(smem, GI + p * IMG, 32 * qs + l31, 2 * ks + h);
+                }
             f32x16 sc, u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag<NP> qrf, grf;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    qrf.p[p] = ld_row8<DP, 3>(smem, QI + p * IMG, 32 * qs + l31, 2 * ks + h);
-                    grf.p[p] = ld_row8<DP, 3>(smem, GI + p * IMG, 32 * qs + l31, 2 * ks + h);
-                }
                 // s[i][j] = u0 + q_i . k_j (rows = queries, column = this lane's key);  u[i][j] = gt_i . v_j - cw_i
-                sc = ks == 0 ? s_chain_head<NP, UNIT>(qrf, kf[0], scinit) : mfma32_parts<NP, NP>(qrf, kf[ks], sc);
-                u = mfma32_parts<NP, NP>(grf, vf[ks], ks == 0 ? ucinit : u);
+                sc = ks == 0 ? s_chain_head<NP, UNIT>(qrf[0], kf[0], scinit) : mfma32_parts<NP, NP>(qrf[ks], kf[ks], sc);
+                u = mfma32_parts<NP, NP>(grf[ks], vf[ks], ks == 0 ? ucinit : u);
             }
             Frag<NPP> pwf[2], dsf[2];
             {
@@ -334,18 +373,28 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
                 pack_tile<NPP>(pw, pwf);
                 pack_tile<NPP>(ds, dsf);
             }
+            Frag<NP> gtf[2][DT], qtf[2][DT];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        gtf[s][t].p[p] = ld_tr8_32<DP, SWT>(smem, GTI + p * TIMG, 32 * qs + 16 * s, 32 * t, lane);
+                        qtf[s][t].p[p] = ld_tr8_32<DP, SWT>(smem, QTI + p * TIMG, 32 * qs + 16 * s, 32 * t, lane);
+                    }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-                    Frag<NP> gtf, qtf;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        gtf.p[p] = ld_tr8_32<DP, 3>(smem, GI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
-                        qtf.p[p] = ld_tr8_32<DP, 3>(smem, QI + p * IMG, 32 * qs + 16 * s, 32 * t, lane);
+                    // dV^T[d][j] += gt[i][d] P'_ij ;  dK^T[m][j] += Q[i][m] dS'_ij
+                    if constexpr (ACC_A) {
+                        mfma32_parts_acc<NP, NPP>(dvacc[t], gtf[s][t], pwf[s]);
+                        mfma32_parts_acc<NP, NPP>(dkacc[t], qtf[s][t], dsf[s]);
+                    } else {
+                        dvacc[t] = mfma32_parts<NP, NPP>(gtf[s][t], pwf[s], dvacc[t]);
+                        dkacc[t] = mfma32_parts<NP, NPP>(qtf[s][t], dsf[s], dkacc[t]);
                     }
-                    dvacc[t] = mfma32_parts<NP, NPP>(gtf, pwf[s], dvacc[t]);        // dV^T[d][j] += gt[i][d] P'_ij
-                    dkacc[t] = mfma32_parts<NP, NPP>(qtf, dsf[s], dkacc[t]);        // dK^T[m][j] += Q[i][m] dS'_ij
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -393,6 +442,10 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
         tile(it, (it - it0) & 1, std::true_type{});
         __syncthreads();
     }
+    if constexpr (ACC_A) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) { acc_fence(dkacc[t]); acc_fence(dvacc[t]); }
+    }
     // dK_j = a e1 sum_i dS'_ij q_i ;  dV_j = e2 sum_i P'_ij gt_i   (e1, e2: see the file header)
     const float e1 = (P == 2 && !UNIT) ? prm.a : 1.0f;
     const float e2 = (P == 1 ? 1.0f : 0.5f) * (UNIT ? 1.0f : (P == 1 ? prm.a : prm.a * prm.a));
@@ -403,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 template <int DP, int P, typename TIN, int NW, int MB, bool UNIT>
 static int launch_bwd32_dq(Quad32BwdParams prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
-    constexpr int st_q = 2 * 2 * NP * img_bytes<DP, 3>(), epi = NW * 4096;
+    constexpr int st_q = 2 * ((DP == 128 && NP == 1) ? NP * (2 * img_bytes<DP, 1>() + img_bytes<DP, 2>()) : 2 * NP * img_bytes<DP, 3>()), epi = NW * 4096;
     constexpr int lds_q = st_q > epi ? st_q : epi;
     auto kq = bwd32_dq_kernel<DP, P, TIN, NW, MB, UNIT>;
     static bool attr_set = false;
@@ -419,7 +472,7 @@ static int launch_bwd32_dq(Quad32BwdParams prm, hipStream_t stream) {
 template <int DP, int P, typename TIN, int NW, bool UNIT>
 static int launch_bwd32_dkv(Quad32BwdParams prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
-    constexpr int st_kv = 2 * (2 * NP * img_bytes<DP, 3>() + 256), epi = NW * 4096;
+    constexpr int st_kv = 2 * (((DP == 128 && NP == 1) ? 2 * NP * (img_bytes<DP, 1>() + img_bytes<DP, 2>()) : 2 * NP * img_bytes<DP, 3>()) + 256), epi = NW * 4096;
     constexpr int lds_kv = st_kv > epi ? st_kv : epi;
     auto kkv = bwd32_dkv_kernel<DP, P, TIN, NW, UNIT>;
     static bool attr_set = false;

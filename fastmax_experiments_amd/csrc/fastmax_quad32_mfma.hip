@@ -2,8 +2,8 @@
 //
 // Same function as fastmax_quad_mfma.hip (o_i = sum_j f(a q_i.k_j) v_j / g_i; reference: attention_mechanisms/fastmax.py:184-322,
 // both p, masked / unmasked, N_q != N_k); this is the throughput form for long sequences:
-//   * a wave owns 32 queries and NW waves (4 or 8) share every 64-key K / V tile, so one LDS fragment read (1 KiB)
-//     feeds a 32x32x16 MFMA (32 K MAC) instead of a 16x16x32 one (16 K MAC): half the LDS traffic per flop
+//   * a wave owns QB blocks of 32 queries and NW waves (4 or 8) share every 64-key K / V tile, so one LDS fragment read
+//     (1 KiB) feeds QB 32x32x16 MFMAs (32 K MAC each) instead of a 16x16x32 one (16 K MAC)
 //   * Q fragments are loaded once from global memory straight into registers (no Q image)
 //   * K / V tiles are double-buffered in LDS; tile t+1 is written from registers right after the single barrier of
 //     tile t and tile t+2 is requested immediately (one barrier per tile, loads one full tile ahead)
@@ -19,6 +19,8 @@
 //     5.2 before, none of them packed-f32 (v_pk_* beside MFMAs costs 3-4x its issue slot on gfx950).
 //   * K / V tiles ride on buffer descriptors whose record count is the head's own byte range: rows past N_k and padded
 //     head columns read as zero in hardware, a tile request is four loads and four integer adds
+//   * QB = 2 (bf16, D <= 64): two independent query blocks per wave give the wave its own matrix work to issue while
+//     the vector ALU turns the other block's scores into P, and halve fragment reads, staging and barriers per MFMA
 // 32x32x16 layouts (A: row = lane&31, k = 8(lane>>5)+j; B: col = lane&31, same k; C: col = lane&31,
 // row(i) = (i&3) + 8(i>>2) + 4(lane>>5)).
 #include "fastmax_mfma32_common.h"
@@ -29,16 +31,6 @@
 
 namespace fastmax {
 
-#ifdef FASTMAX_QUAD32_STAMPS
-// diagnostic build only (tools/quad32_stamps.py): per workgroup, wave 0's issue-time split of the D <= 64 tile loop
-__device__ unsigned long long* g_q32_stamps = nullptr;
-#define Q32_STAMP(var) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (var) += now_ - q32_t; q32_t = now_; } while (0)
-#else
-#define Q32_STAMP(var) do { } while (0)
-#endif
-
-#define QUAD32_DEFAULT_SCHED(DP) ((DP) == 128 ? 1 : 0)
-
 struct Quad32Params {
     const void *q, *k, *v;
     Strides3 qs, ks, vs;
@@ -48,8 +40,9 @@ struct Quad32Params {
     float a, g0;
 };
 
-template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks() {
-    // bf16 D<=64 with a 16-bit result needs ~166 registers: three 4-wave workgroups per CU; everything else two waves / SIMD
+template <int DP, typename TIN, int NPP, int NW, int QB> constexpr int quad32_min_blocks() {
+    if (QB == 2) return 2;                                        // ~230 registers: two 4-wave workgroups per CU
+    // bf16 D<=64 with a 16-bit result needs ~150 registers: three 4-wave workgroups per CU; everything else two waves / SIMD
     if (DP == 64 && InTraits<TIN>::NP == 1 && NPP == 1) return NW == 8 ? 1 : 3;
     return NW == 8 ? 1 : 2;
 }
@@ -57,13 +50,15 @@ template <int DP, typename TIN, int NPP, int NW> constexpr int quad32_min_blocks
 // 1-D grid of nqt * BH workgroups; block = 64 NW threads; dynamic LDS = max(2 stages of K,V images, NW * 4 KiB)
 // UNIT: Q is scaled by a on load and the score chain starts at the inline constant 1.0 (u = 1 + a q.k); otherwise the
 // chain starts at a register tile holding 1/a (u = 1/a + q.k) -- single-part operands whose scale is not a power of two
-template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED>
-__global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) void fwd_quad32_kernel(Quad32Params prm) {
+// SCHED: issue order of a tile, see tile1 / tile2
+template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED, int QB>
+__global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>())) void fwd_quad32_kernel(Quad32Params prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
-    constexpr int NT = 64 * NW, QT = 32 * NW;
+    constexpr int NT = 64 * NW, QW = 32 * QB, QT = QW * NW;
     constexpr int KIMG = img_bytes<DP, 1>(), VIMG = img_bytes<DP, 2>(), STAGE = NP * (KIMG + VIMG);
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = 64 / RPP;
     static_assert(RPP <= 64 && NPASS >= 1, "staging map");
+    static_assert(QB == 1 || (NP == 1 && NPP == 1), "two query blocks per wave: single-part operands only");
     constexpr int KS = DP / 16, DT = DP / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,17 +82,23 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     const int b = bh / prm.H, hh = bh % prm.H;
     const int D = prm.D, Nq = prm.Nq, Nk = prm.Nk;
     const bool causal = prm.causal != 0;
-    const int i0 = qt * QT, qw0 = i0 + 32 * w, myq = qw0 + l31;
+    const int i0 = qt * QT, qw0 = i0 + QW * w;
     const TIN* qb = reinterpret_cast<const TIN*>(prm.q) + (int64_t)b * prm.qs.sb + (int64_t)hh * prm.qs.sh;
     const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)hh * prm.ks.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)hh * prm.vs.sh;
     const int srow = tid / COLS, scol = tid % COLS;
 
-    Frag<NP> qf[KS];
+    Frag<NP> qf[QB][KS];
+    int klim[QB];                                                     // last key a lane's query may see
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if constexpr (UNIT) qf[ks] = load_q_frag_scaled<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D, prm.a);
-        else qf[ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+    for (int qb_ = 0; qb_ < QB; ++qb_) {
+        const int myq = qw0 + 32 * qb_ + l31;
+        klim[qb_] = causal ? min(myq, Nk - 1) : Nk - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (UNIT) qf[qb_][ks] = load_q_frag_scaled<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D, prm.a);
+            else qf[qb_][ks] = load_q_frag<TIN>(qb, prm.qs.sn, myq, Nq, 16 * ks + 8 * h, D);
+        }
     }
 
     u32x4 rk[NPASS], rv[NPASS];
@@ -115,38 +116,38 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     };
     const int nkt = causal ? min((i0 + QT + 63) / 64, (Nk + 63) / 64) : (Nk + 63) / 64;
 
-    f32x16 oacc[DT];
+    f32x16 oacc[QB][DT];
+    float gsum[QB][4];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int qb_ = 0; qb_ < QB; ++qb_) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
-    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[qb_][dt][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gsum[qb_][i] = 0.f;
+    }
     // u = u0 + (scaled) q.k out of the score chain; f = fscale * (p == 1 ? u : u u + c0)
     const float u0 = UNIT ? 1.0f : 1.0f / prm.a, c0 = u0 * u0;
     const float fscale = (P == 1 ? 1.0f : 0.5f) * (UNIT ? 1.0f : (P == 1 ? prm.a : prm.a * prm.a));
     f32x16 cinit;                                                     // dead when UNIT
 #pragma unroll
     for (int i = 0; i < 16; ++i) cinit[i] = u0;
-#ifdef FASTMAX_QUAD32_STAMPS
-    unsigned long long q32_t = __builtin_amdgcn_s_memtime(), st_qk = 0, st_poly = 0, st_pv = 0, st_adv = 0, st_bar = 0, st_tiles = 0, st_wait = 0, st_commit = 0;
-    const unsigned long long q32_t0 = q32_t;
-#endif
 
-    const int klim = causal ? min(myq, Nk - 1) : Nk - 1;
-    // f(a s) of one S^T tile (32 keys x 32 queries) -> the two B fragments (16 keys each) of the P^T operand
-    auto poly = [&](const f32x16& sc, int key0, auto masked_tag, Frag<NPP> (&pf)[2]) {
+    // f of one S^T tile (32 keys x 32 queries of block qb_) -> the two B fragments (16 keys each) of the P^T operand
+    auto poly = [&](const f32x16& sc, int qb_, int key0, auto masked_tag, Frag<NPP> (&pf)[2]) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         float pv[16];
-        // masked tiles: element i of this lane is key key0 + 4h + (i&3) + 8(i>>2); it counts while key <= klim
-        // (klim = last key this lane's query may see): one compare against a compile-time row offset per element
-        const int rel = klim - key0 - 4 * h;
+        // masked tiles: element i of this lane is key key0 + 4h + (i&3) + 8(i>>2); it counts while key <= klim: one
+        // compare against a compile-time row offset per element
+        const int rel = klim[qb_] - key0 - 4 * h;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float x = sc[i];
             if constexpr (P == 2) x = fmaf(x, x, c0);
             if constexpr (MASKED) x = ((i & 3) + 8 * (i >> 2) <= rel) ? x : 0.f;
             pv[i] = x;
-            gsum[i & 3] += x;
+            gsum[qb_][i & 3] += x;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -163,16 +164,26 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
             }
         }
     };
+    // S^T chain of one key half for query block qb_: u0 + K(half) Q^T
+    auto qk_chain = [&](const Frag<NP> (&kf)[KS], int qb_) {
+        f32x16 sc;
+        if constexpr (UNIT) sc = mfma32_parts_c1<NP, NP>(kf[0], qf[qb_][0]);
+        else sc = mfma32_parts<NP, NP>(kf[0], qf[qb_][0], cinit);
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks) sc = mfma32_parts<NP, NP>(kf[ks], qf[qb_][ks], sc);
+        return sc;
+    };
+    constexpr int QKM = KS * (NP == 2 ? 3 : 1);                       // MFMAs of one S chain
+    constexpr int PVM = 2 * DT * (1 + (NP == 2) + (NPP == 2));        // MFMAs of one key half of O^T += V^T P^T
 
-    // One 64-key tile for this wave's 32 queries.  MASKED = the tile touches the causal diagonal or runs past N_k.
-    // Software pipeline inside the wave (the two 32-key halves h0, h1 of the tile):
+    // One 64-key tile for one query block.  MASKED = the tile touches the causal diagonal or runs past N_k.
+    // SCHED 1: software pipeline inside the wave (the two 32-key halves h0, h1 of the tile)
     //     A: S(h0) = K(h0) Q^T            B: S(h1) = K(h1) Q^T  ||  P(h0) = f(S(h0)) on the vector ALU
     //     C: O^T += V(h0)^T P(h0)^T  ||  P(h1) = f(S(h1))       D: O^T += V(h1)^T P(h1)^T
-    // B and C are issued as {1 MFMA, a few VALU} groups so the polynomial hides in the matrix pipe's shadow.
-    auto tile = [&](int kt, int stage, auto masked_tag) {
+    // with B and C issued as {1 MFMA, a few VALU} groups; SCHED 0: both S chains, then per half the V^T fragments requested,
+    // the polynomial walled off, the O^T product (compiler order otherwise)
+    auto tile1 = [&](int kt, int stage, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        constexpr int QKM = KS * (NP == 2 ? 3 : 1);                   // MFMAs of one S chain
-        constexpr int PVM = 2 * DT * (1 + (NP == 2) + (NPP == 2));    // MFMAs of one key half of O^T += V^T P^T
         constexpr int VPOLY = (P == 2 ? 16 : 0) + 16 + (NPP == 2 ? 40 : 8) + (MASKED ? 32 : 0);   // VALU of one poly()
         const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
         f32x16 sc[2];
@@ -192,84 +203,129 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
 #pragma unroll
                     for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
         };
-        auto qk = [&](int jt) {
-            if constexpr (UNIT) {
-                sc[jt] = mfma32_parts_c1<NP, NP>(kf[jt][0], qf[0]);
-            } else {
-                sc[jt] = mfma32_parts<NP, NP>(kf[jt][0], qf[0], cinit);
-            }
-#pragma unroll
-            for (int ks = 1; ks < KS; ++ks) sc[jt] = mfma32_parts<NP, NP>(kf[jt][ks], qf[ks], sc[jt]);
-        };
         Frag<NPP> pf[2][2];
         auto pv = [&](int jt) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32_parts<NP, NPP>(vf[jt][s][dt], pf[jt][s], oacc[dt]);
+                for (int dt = 0; dt < DT; ++dt) oacc[0][dt] = mfma32_parts<NP, NPP>(vf[jt][s][dt], pf[jt][s], oacc[0][dt]);
         };
         if constexpr (SCHED == 1) {
-            // A
-            qk(0);
+            sc[0] = qk_chain(kf[0], 0);
             vread(0);
             __builtin_amdgcn_sched_barrier(0);
-            // B
-            qk(1);
-            poly(sc[0], k0, masked_tag, pf[0]);
+            sc[1] = qk_chain(kf[1], 0);
+            poly(sc[0], 0, k0, masked_tag, pf[0]);
 #pragma unroll
             for (int i = 0; i < QKM; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, (VPOLY + QKM - 1) / QKM, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // C
             vread(1);
             pv(0);
-            poly(sc[1], k0 + 32, masked_tag, pf[1]);
+            poly(sc[1], 0, k0 + 32, masked_tag, pf[1]);
 #pragma unroll
             for (int i = 0; i < PVM; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                 __builtin_amdgcn_sched_group_barrier(0x002, (VPOLY + PVM - 1) / PVM, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // D
             pv(1);
         } else {
-            // both S chains first, then per half: V^T fragments requested, polynomial walled off, O^T product
-            qk(0);
-            qk(1);
-#ifdef FASTMAX_QUAD32_STAMPS
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            Q32_STAMP(st_qk);
+            sc[0] = qk_chain(kf[0], 0);
+            sc[1] = qk_chain(kf[1], 0);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 vread(jt);
                 __builtin_amdgcn_sched_barrier(0);
-                poly(sc[jt], k0 + 32 * jt, masked_tag, pf[jt]);
+                poly(sc[jt], 0, k0 + 32 * jt, masked_tag, pf[jt]);
                 __builtin_amdgcn_sched_barrier(0);
-                Q32_STAMP(st_poly);
                 pv(jt);
-#ifdef FASTMAX_QUAD32_STAMPS
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                Q32_STAMP(st_pv);
             }
         }
+    };
+
+    // One 64-key tile for TWO query blocks a, b (single-part operands).  Six phases; in every phase but the first and the
+    // last the matrix instructions of one (block, key half) pair are issued beside the polynomial of another:
+    //     1: S(a,h0) S(b,h0)     2: S(a,h1) || P(a,h0)     3: S(b,h1) || P(b,h0)
+    //     4: O(a) += V(h0)^T P(a,h0) || P(a,h1)     5: O(b) += V(h0)^T P(b,h0) || P(b,h1)     6: O(a), O(b) += V(h1)^T P(.,h1)
+    // K fragments of a key half serve both blocks, V^T fragments likewise.  SCHED 1 pins each phase's issue as
+    // {1 MFMA, VPOLY / 4 VALU} groups; SCHED 0 only fences the phases.
+    auto tile2 = [&](int kt, int stage, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int VPOLY = (P == 2 ? 16 : 0) + 16 + 8 + (MASKED ? 32 : 0);
+        const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
+        constexpr int B1 = QB - 1;                                   // second block (index 0 where this lambda is dead code)
+        auto kread = [&](int jt, Frag<NP> (&kf)[KS]) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[ks].p[0] = ld_row8<DP, 1>(smem, KI, 32 * jt + l31, 2 * ks + h);
+        };
+        auto vread = [&](int jt, Frag<NP> (&vf)[2][DT]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) vf[s][dt].p[0] = ld_tr8_32<DP>(smem, VI, 32 * jt + 16 * s, 32 * dt, lane);
+        };
+        auto pv = [&](int qb_, const Frag<NP> (&vf)[2][DT], const Frag<NPP> (&pf)[2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[qb_][dt] = mfma32_parts<NP, NPP>(vf[s][dt], pf[s], oacc[qb_][dt]);
+        };
+        auto group = [&](auto id_tag) {
+            constexpr int ID = decltype(id_tag)::value;
+            if constexpr (SCHED == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, ID);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (VPOLY + 3) / 4, ID);
+                }
+            }
+        };
+        Frag<NP> kf0[KS], kf1[KS], vf0[2][DT], vf1[2][DT];
+        Frag<NPP> pa0[2], pb0[2], pa1[2], pb1[2];
+        kread(0, kf0);
+        kread(1, kf1);
+        // 1
+        f32x16 sa0 = qk_chain(kf0, 0);
+        f32x16 sb0 = qk_chain(kf0, B1);
+        vread(0, vf0);
+        __builtin_amdgcn_sched_barrier(0);
+        // 2
+        f32x16 sa1 = qk_chain(kf1, 0);
+        poly(sa0, 0, k0, masked_tag, pa0);
+        group(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // 3
+        f32x16 sb1 = qk_chain(kf1, B1);
+        poly(sb0, B1, k0, masked_tag, pb0);
+        group(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // 4
+        vread(1, vf1);
+        pv(0, vf0, pa0);
+        poly(sa1, 0, k0 + 32, masked_tag, pa1);
+        group(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // 5
+        pv(B1, vf0, pb0);
+        poly(sb1, B1, k0 + 32, masked_tag, pb1);
+        group(std::integral_constant<int, 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // 6
+        pv(0, vf1, pa1);
+        pv(B1, vf1, pb1);
+    };
+    auto tile = [&](int kt, int stage, auto masked_tag) {
+        if constexpr (QB == 2) tile2(kt, stage, masked_tag);
+        else tile1(kt, stage, masked_tag);
     };
     // staging half of an iteration: tile kt+1 goes to the other stage (last read before the previous barrier), tile kt+2
     // is requested
     auto advance = [&](int kt) {
         if (kt + 1 < nkt) {
-#ifdef FASTMAX_QUAD32_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // diagnostic: the wait for tile kt+1's loads on its own
-            Q32_STAMP(st_wait);
-#endif
             commit((kt & 1) ^ 1);
-#ifdef FASTMAX_QUAD32_STAMPS
-            __builtin_amdgcn_sched_barrier(0);
-            Q32_STAMP(st_commit);
-#endif
             if (kt + 2 < nkt) request(kt + 2);
         }
     };
@@ -277,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     // [n_act, nkt) lie wholly above the diagonal of this wave's queries (other waves of the workgroup still need them)
     const int n_full = Nk / 64;
     const int n_plain = causal ? min((qw0 + 1) / 64, n_full) : n_full;
-    const int n_act = causal ? min(nkt, (qw0 + 31) / 64 + 1) : nkt;
+    const int n_act = causal ? min(nkt, (qw0 + QW - 1) / 64 + 1) : nkt;
 
     request(0);
     commit(0);
@@ -285,16 +341,8 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
     __syncthreads();
     int kt = 0;
     for (; kt < n_plain; ++kt) {
-        Q32_STAMP(st_bar);
         advance(kt);
-#ifdef FASTMAX_QUAD32_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        Q32_STAMP(st_adv);
         tile(kt, kt & 1, std::false_type{});
-#ifdef FASTMAX_QUAD32_STAMPS
-        ++st_tiles;
-#endif
         __syncthreads();
     }
     for (; kt < n_act; ++kt) {
@@ -307,51 +355,58 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW>())) v
         __syncthreads();
     }
 
-#ifdef FASTMAX_QUAD32_STAMPS
-    if (g_q32_stamps && tid == 0) {
-        unsigned long long* rec = g_q32_stamps + 8 * (int64_t)blockIdx.x;
-        rec[0] = st_tiles; rec[1] = st_qk; rec[2] = st_poly; rec[3] = st_pv; rec[4] = st_adv; rec[5] = st_bar;
-        rec[6] = st_wait; rec[7] = st_commit;
+#pragma unroll
+    for (int qb_ = 0; qb_ < QB; ++qb_) {
+        const int myq = qw0 + 32 * qb_ + l31;
+        float gs = (gsum[qb_][0] + gsum[qb_][1]) + (gsum[qb_][2] + gsum[qb_][3]);
+        gs += __shfl_xor(gs, 32, 64);
+        gs *= fscale;
+        // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
+        const float gval = causal ? gs : gs - (float)Nk + prm.g0;
+        if (myq < Nq && prm.g && h == 0) prm.g[(int64_t)bh * Nq + myq] = gval;
+        const float ginv = fscale / gval;
+        store_tile32_t<DT>(smem + w * 4096, oacc[qb_], ginv, lane, prm.o, prm.out_dtype, (int64_t)bh * Nq, qw0 + 32 * qb_, Nq, D);
     }
-#endif
-    float gs = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
-    gs += __shfl_xor(gs, 32, 64);
-    gs *= fscale;
-    // unmasked: rowsum(f) carries the constant N_k; the reference's constant is g0 (fastmax.py:271, fastmax_hack.py:21)
-    const float gval = causal ? gs : gs - (float)Nk + prm.g0;
-    if (myq < Nq && prm.g && h == 0) prm.g[(int64_t)bh * Nq + myq] = gval;
-    const float ginv = fscale / gval;
-    store_tile32_t<DT>(smem + w * 4096, oacc, ginv, lane, prm.o, prm.out_dtype, (int64_t)bh * Nq, qw0, Nq, D);
 }
 
-template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED>
+template <int DP, int P, typename TIN, int NPP, int NW, bool UNIT, int SCHED, int QB>
 static int launch_quad32_w(Quad32Params prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
     constexpr int stages = 2 * NP * (img_bytes<DP, 1>() + img_bytes<DP, 2>()), epi = NW * 4096;
     constexpr int lds = stages > epi ? stages : epi;
-    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW, UNIT, SCHED>;
+    auto kern = fwd_quad32_kernel<DP, P, TIN, NPP, NW, UNIT, SCHED, QB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    prm.nqt = (prm.Nq + 32 * NW - 1) / (32 * NW);
+    prm.nqt = (prm.Nq + 32 * QB * NW - 1) / (32 * QB * NW);
     hipLaunchKernelGGL(kern, dim3(prm.nqt * prm.BH), dim3(64 * NW), lds, stream, prm);
     return (int)hipGetLastError();
 }
 template <int DP, int P, typename TIN, int NPP, bool UNIT>
 static int launch_quad32_n(const Quad32Params& prm, hipStream_t stream) {
-    static const int forced = [] { const char* e = getenv("FASTMAX_QUAD32_NW"); return e ? atoi(e) : 0; }();
     static const int sched = [] { const char* e = getenv("FASTMAX_QUAD32_SCHED"); return e ? atoi(e) : -1; }();
-    const int nw = forced ? forced : ((DP == 64 && InTraits<TIN>::NP == 1) ? 4 : 8);
-    // issue order of a tile (see the kernel): 1 = polynomial of one key half in the shadow of the other half's matrix
-    // instructions (grouped issue), 0 = compiler order with the polynomial walled off
-    constexpr int DEF_SCHED = QUAD32_DEFAULT_SCHED(DP);
-    const int sc = sched >= 0 ? sched : DEF_SCHED;
-    if (sc == 1)
-        return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8, UNIT, 1>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 1>(prm, stream);
-    return nw == 8 ? launch_quad32_w<DP, P, TIN, NPP, 8, UNIT, 0>(prm, stream) : launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 0>(prm, stream);
+    static const int qbenv = [] { const char* e = getenv("FASTMAX_QUAD32_QB"); return e ? atoi(e) : 0; }();
+    constexpr bool SINGLE = InTraits<TIN>::NP == 1 && NPP == 1;
+    if constexpr (SINGLE && DP == 64) {
+        // bf16, D <= 64, 16-bit result: two query blocks per wave once a head has enough query tiles of 256
+        const int qb = qbenv ? qbenv : (prm.Nq >= 1024 ? 2 : 1);
+        if (qb == 2) {
+            if (sched == 0) return launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 0, 2>(prm, stream);
+            return launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 1, 2>(prm, stream);
+        }
+        if (sched == 1) return launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 1, 1>(prm, stream);
+        return launch_quad32_w<DP, P, TIN, NPP, 4, UNIT, 0, 1>(prm, stream);
+    } else {
+        // everything else: one query block per wave; eight waves unless the operands are bf16 at D <= 64; D = 128 with the
+        // grouped issue order
+        constexpr int NWD = (DP == 64 && InTraits<TIN>::NP == 1) ? 4 : 8;
+        constexpr int DEF_SCHED = DP == 128 ? 1 : 0;
+        if ((sched >= 0 ? sched : DEF_SCHED) == 1) return launch_quad32_w<DP, P, TIN, NPP, NWD, UNIT, 1, 1>(prm, stream);
+        return launch_quad32_w<DP, P, TIN, NPP, NWD, UNIT, 0, 1>(prm, stream);
+    }
 }
 // a = 2^e exactly: scaling single-part (bf16) query fragments by it loses nothing
 static bool is_pow2(float a) { int e; return a > 0.f && frexpf(a, &e) == 0.5f; }
@@ -402,10 +457,3 @@ int launch_fwd_quad32(const FwdArgs& a) {
 }
 
 }  // namespace fastmax
-
-#ifdef FASTMAX_QUAD32_STAMPS
-extern "C" int fastmax_hip_debug_quad32_stamps(void* buffer) {
-    unsigned long long* p = reinterpret_cast<unsigned long long*>(buffer);
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(fastmax::g_q32_stamps), &p, sizeof(p));
-}
-#endif

@@ -130,11 +130,11 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
 
     u32x4 rk[NPASS], rv[NPASS];
     const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
-    auto request = [&](int kt) {
+    auto request = [&](int kt) __attribute__((always_inline)) {
         kload.load(kt, rk);
         vload.load(kt, rv);
     };
-    auto commit = [&](int stage) {
+    auto commit = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             stage_piece<DP, TIN, SWR>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
-    auto tile = [&](int kt, int stage, auto masked_tag) {
+    auto tile = [&](int kt, int stage, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int KI = stage * STAGE, VI = KI + NP * IMG, KT = DUAL ? KI + KTO : KI, k0 = kt * 64;
         constexpr int TIMG = DUAL ? IMGT : IMG;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
                 }
         }
     };
-    auto advance = [&](int kt) {
+    auto advance = [&](int kt) __attribute__((always_inline)) {
         if (kt + 1 < nkt) {
             commit((kt & 1) ^ 1);
             if (kt + 2 < nkt) request(kt + 2);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
     constexpr int NT = 64 * NW, KT = 32 * NW;
     // Q and gt are both read by rows (S, U chains) and transposed (dK, dV products): one dual-use XOR image each at D <= 64,
     // a padded row image + a padded transposed-read image each at D = 128 (see bwd32_dq_kernel)
-    constexpr bool DUAL = DP == 128 && NP == 1;                            // two-part operands: the images would not fit
+    constexpr bool DUAL = DP == 128 && NP == 1;        // two-part operands: the images would not fit
     constexpr int SWR = DUAL ? 1 : 3, SWT = DUAL ? 2 : 3;
     constexpr int IMG = img_bytes<DP, SWR>(), IMGT = DUAL ? img_bytes<DP, SWT>() : 0;
     constexpr int TRO = 2 * NP * IMG, CWO = TRO + 2 * NP * IMGT, STAGE = CWO + 256;   // Q rows, gt rows[, Q tr, gt tr], -cw[64]
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
     u32x4 rq[NPASS], rg[NPASS];
     float rcw = 0.f;
     const BufTileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, srow, scol), gload(gb, D, Nq, D, srow, scol);
-    auto request = [&](int it) {
+    auto request = [&](int it) __attribute__((always_inline)) {
         qload.load(it, rq);
         gload.load(it, rg);
         if (tid < 64) {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
             rcw = -prm.cw[(int64_t)bh * Nq + gc];
         }
     };
-    auto commit = [&](int stage) {
+    auto commit = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             stage_piece<DP, TIN, SWR>(smem, stage * STAGE, srow + ps * RPP, scol, rq[ps]);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkacc[t][i] = 0.f; dvacc[t][i] = 0.f; }
 
-    auto tile = [&](int it, int stage, auto masked_tag) {
+    auto tile_plain = [&](int it, int stage, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int QI = stage * STAGE, GI = QI + NP * IMG, CS = QI + CWO;
         const int QTI = DUAL ? QI + TRO : QI, GTI = DUAL ? QTI + NP * IMGT : GI;
@@ -399,7 +399,136 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto advance = [&](int it) {
+    // Single-part operands: the same tile as a software pipeline over its two 32-query halves, so that the vector ALU's turn on
+    // one half's score tiles runs beside the other half's matrix instructions (a wave alone on its SIMD has nobody else to fill
+    // the matrix pipe while it multiplies and packs):
+    //     S,U(h0)  |  S,U(h1) || f(h0)  |  dV,dK += (h0) || f(h1)  |  dV,dK += (h1)
+    // In the two middle phases one score element is processed after every matrix instruction (sched_barrier fences pin the
+    // order); the fragments of a phase are requested one phase ahead.
+    auto tile_pipe = [&](int it, int stage, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int QI = stage * STAGE, GI = QI + NP * IMG, CS = QI + CWO;
+        const int QTI = DUAL ? QI + TRO : QI, GTI = DUAL ? QTI + NP * IMGT : GI;
+        constexpr int TIMG = DUAL ? IMGT : IMG;
+        constexpr int NCH = 2 * KS, NAC = 4 * DT;                   // matrix instructions of a chain phase / an accumulate phase
+        Frag<NP> qrf[2][KS], grf[2][KS], gtf[2][2][DT], qtf[2][2][DT];
+        f32x16 sc[2], u[2];
+        float pw[2][16], ds[2][16];
+        Frag<NPP> pwf[2][2], dsf[2][2];
+        auto readG = [&](int qs) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ig = 0; ig < 4; ++ig) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(smem + CS + (32 * qs + 8 * ig + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[qs][4 * ig + e] = c4[e];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qrf[qs][ks].p[0] = ld_row8<DP, SWR>(smem, QI, 32 * qs + l31, 2 * ks + h);
+                grf[qs][ks].p[0] = ld_row8<DP, SWR>(smem, GI, 32 * qs + l31, 2 * ks + h);
+            }
+        };
+        auto readT = [&](int qs, int s_) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                gtf[qs][s_][t].p[0] = ld_tr8_32<DP, SWT>(smem, GTI, 32 * qs + 16 * s_, 32 * t, lane);
+                qtf[qs][s_][t].p[0] = ld_tr8_32<DP, SWT>(smem, QTI, 32 * qs + 16 * s_, 32 * t, lane);
+            }
+        };
+        // m-th matrix instruction of a chain phase: k-step m/2 of S (even m) or U (odd m)
+        auto chain_step = [&](int qs, int m) __attribute__((always_inline)) {
+            const int ks = m >> 1;
+            if ((m & 1) == 0) sc[qs] = ks == 0 ? s_chain_head<NP, UNIT>(qrf[qs][0], kf[0], scinit) : mfma32_parts<NP, NP>(qrf[qs][ks], kf[ks], sc[qs]);
+            else u[qs] = mfma32_parts<NP, NP>(grf[qs][ks], vf[ks], u[qs]);
+        };
+        // m-th matrix instruction of an accumulate phase: (s, t, dV | dK)
+        auto acc_step = [&](int qs, int m) __attribute__((always_inline)) {
+            const int s_ = m / (2 * DT), t = (m >> 1) % DT;
+            if ((m & 1) == 0) {
+                if constexpr (ACC_A) mfma32_parts_acc<NP, NPP>(dvacc[t], gtf[qs][s_][t], pwf[qs][s_]);
+                else dvacc[t] = mfma32_parts<NP, NPP>(gtf[qs][s_][t], pwf[qs][s_], dvacc[t]);
+            } else {
+                if constexpr (ACC_A) mfma32_parts_acc<NP, NPP>(dkacc[t], qtf[qs][s_][t], dsf[qs][s_]);
+                else dkacc[t] = mfma32_parts<NP, NPP>(qtf[qs][s_][t], dsf[qs][s_], dkacc[t]);
+            }
+        };
+        auto valu_elem = [&](int qs, int i) __attribute__((always_inline)) {
+            float pwv = sc[qs][i], dsv = u[qs][i];
+            if constexpr (P == 2) {
+                pwv = fmaf(sc[qs][i], sc[qs][i], c0);
+                dsv *= sc[qs][i];
+            }
+            if constexpr (MASKED) {
+                const int lo = qlo - (it * 64 + 32 * qs) - 4 * h, hi = Nq - 1 - (it * 64 + 32 * qs) - 4 * h;
+                const int r = (i & 3) + 8 * (i >> 2);
+                const bool keep = r >= lo && r <= hi;
+                pwv = keep ? pwv : 0.f;
+                dsv = keep ? dsv : 0.f;
+            }
+            pw[qs][i] = pwv;
+            ds[qs][i] = dsv;
+        };
+        auto pack_half = [&](int qs, int s_) __attribute__((always_inline)) {
+            const f32x4 p0 = {pw[qs][8 * s_], pw[qs][8 * s_ + 1], pw[qs][8 * s_ + 2], pw[qs][8 * s_ + 3]};
+            const f32x4 p1 = {pw[qs][8 * s_ + 4], pw[qs][8 * s_ + 5], pw[qs][8 * s_ + 6], pw[qs][8 * s_ + 7]};
+            const f32x4 d0 = {ds[qs][8 * s_], ds[qs][8 * s_ + 1], ds[qs][8 * s_ + 2], ds[qs][8 * s_ + 3]};
+            const f32x4 d1 = {ds[qs][8 * s_ + 4], ds[qs][8 * s_ + 5], ds[qs][8 * s_ + 6], ds[qs][8 * s_ + 7]};
+            pwf[qs][s_].p[0] = cat4(to_bf16x4(p0), to_bf16x4(p1));
+            dsf[qs][s_].p[0] = cat4(to_bf16x4(d0), to_bf16x4(d1));
+        };
+        // the 16 score elements of a half spread over the NM (8 or 16) matrix instructions of the phase beside it
+        auto valu_slice = [&](int qs, int m, auto nm_tag) __attribute__((always_inline)) {
+            constexpr int EPM = 16 / decltype(nm_tag)::value;
+            static_assert(EPM * decltype(nm_tag)::value == 16, "phase length");
+#pragma unroll
+            for (int e = 0; e < EPM; ++e) {
+                const int i = m * EPM + e;
+                valu_elem(qs, i);
+                if (i == 7) pack_half(qs, 0);
+                if (i == 15) pack_half(qs, 1);
+            }
+        };
+#define Q32_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // reads are requested half a phase ahead of their first use: early enough for a lone wave, late enough that two full
+        // fragment sets are never alive together (D = 128: 64 registers each)
+        readG(0);
+        Q32_FENCE();
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            if (m == NCH / 2) readG(1);
+            chain_step(0, m);
+            if (m == NCH / 2 - 1) Q32_FENCE();
+        }
+        Q32_FENCE();
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            if (m == NCH / 2) readT(0, 0);
+            chain_step(1, m);
+            valu_slice(0, m, std::integral_constant<int, NCH>{});
+            Q32_FENCE();
+        }
+#pragma unroll
+        for (int m = 0; m < NAC; ++m) {
+            if (m == 0) readT(0, 1);
+            if (m == NAC / 2) readT(1, 0);
+            acc_step(0, m);
+            valu_slice(1, m, std::integral_constant<int, NAC>{});
+            Q32_FENCE();
+        }
+#pragma unroll
+        for (int m = 0; m < NAC; ++m) {
+            if (m == 0) readT(1, 1);
+            acc_step(1, m);
+        }
+#undef Q32_FENCE
+    };
+    auto tile = [&](int it, int stage, auto masked_tag) __attribute__((always_inline)) {
+        // one wave per SIMD (D = 128, single-part operands): the explicit pipeline; two waves per SIMD interleave by themselves
+        // and lose 2 % to the fences
+        if constexpr (NP == 1 && DP == 128) tile_pipe(it, stage, masked_tag);
+        else tile_plain(it, stage, masked_tag);
+    };
+    auto advance = [&](int it) __attribute__((always_inline)) {
         if (it + 1 < nqt) {
             commit(((it - it0) & 1) ^ 1);
             if (it + 2 < nqt) request(it + 2);
@@ -488,19 +617,16 @@ static int launch_bwd32_dkv(Quad32BwdParams prm, hipStream_t stream) {
 template <int DP, int P, typename TIN, bool UNIT>
 static int launch_bwd32_n(const Quad32BwdParams& prm, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP;
-    static const int vq = [] { const char* e = getenv("FASTMAX_BWD32_DQ"); return e ? atoi(e) : -1; }();
-    static const int vkv = [] { const char* e = getenv("FASTMAX_BWD32_DKV_NW"); return e ? atoi(e) : 0; }();
+    // measured choices (profiles/r01_quad32_p2_bf16.md, r03_p2_tiles.md): two-part operands at D <= 64 take eight waves per
+    // workgroup; bf16 at D <= 64 four waves and two workgroups per CU (256 registers); D = 128 four waves with the whole
+    // register file (the 256-register cap spills the accumulators into the tile loop)
     int rc;
-    // dQ variants: 0 = 4 waves, two workgroups per CU (256 registers); 1 = 4 waves, one workgroup per CU (whole file);
-    // 2 = 8 waves, one workgroup per CU
-    constexpr int DEF_Q = (DP == 64 && NP == 2) ? 2 : (DP == 64 ? 0 : 1);
-    const int q = vq >= 0 ? vq : DEF_Q;
-    if (q == 2) rc = launch_bwd32_dq<DP, P, TIN, 8, 1, UNIT>(prm, stream);
-    else if (q == 1) rc = launch_bwd32_dq<DP, P, TIN, 4, 1, UNIT>(prm, stream);
-    else rc = launch_bwd32_dq<DP, P, TIN, 4, 2, UNIT>(prm, stream);
+    if constexpr (DP == 64 && NP == 2) rc = launch_bwd32_dq<DP, P, TIN, 8, 1, UNIT>(prm, stream);
+    else if constexpr (DP == 64) rc = launch_bwd32_dq<DP, P, TIN, 4, 2, UNIT>(prm, stream);
+    else rc = launch_bwd32_dq<DP, P, TIN, 4, 1, UNIT>(prm, stream);
     if (rc) return rc;
-    const int nwkv = vkv ? vkv : ((DP == 64 && NP == 2) ? 8 : 4);
-    return nwkv == 8 ? launch_bwd32_dkv<DP, P, TIN, 8, UNIT>(prm, stream) : launch_bwd32_dkv<DP, P, TIN, 4, UNIT>(prm, stream);
+    if constexpr (DP == 64 && NP == 2) return launch_bwd32_dkv<DP, P, TIN, 8, UNIT>(prm, stream);
+    else return launch_bwd32_dkv<DP, P, TIN, 4, UNIT>(prm, stream);
 }
 static bool is_pow2(float a) { int e; return a > 0.f && frexpf(a, &e) == 0.5f; }
 template <int DP, int P, typename TIN>

@@ -103,11 +103,11 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
 
     u32x4 rk[NPASS], rv[NPASS];
     const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
-    auto request = [&](int kt) {
+    auto request = [&](int kt) __attribute__((always_inline)) {
         kload.load(kt, rk);
         vload.load(kt, rv);
     };
-    auto commit = [&](int stage) {
+    auto commit = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             stage_piece<DP, TIN, 1>(smem, stage * STAGE, srow + ps * RPP, scol, rk[ps]);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
     //     C: O^T += V(h0)^T P(h0)^T  ||  P(h1) = f(S(h1))       D: O^T += V(h1)^T P(h1)^T
     // with B and C issued as {1 MFMA, a few VALU} groups; SCHED 0: both S chains, then per half the V^T fragments requested,
     // the polynomial walled off, the O^T product (compiler order otherwise)
-    auto tile1 = [&](int kt, int stage, auto masked_tag) {
+    auto tile1 = [&](int kt, int stage, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int VPOLY = (P == 2 ? 16 : 0) + 16 + (NPP == 2 ? 40 : 8) + (MASKED ? 32 : 0);   // VALU of one poly()
         const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
 #pragma unroll
                 for (int p = 0; p < NP; ++p) kf[jt][ks].p[p] = ld_row8<DP, 1>(smem, KI + p * KIMG, 32 * jt + l31, 2 * ks + h);
         Frag<NP> vf[2][2][DT];
-        auto vread = [&](int jt) {
+        auto vread = [&](int jt) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
                     for (int p = 0; p < NP; ++p) vf[jt][s][dt].p[p] = ld_tr8_32<DP>(smem, VI + p * VIMG, 32 * jt + 16 * s, 32 * dt, lane);
         };
         Frag<NPP> pf[2][2];
-        auto pv = [&](int jt) {
+        auto pv = [&](int jt) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
     //     4: O(a) += V(h0)^T P(a,h0) || P(a,h1)     5: O(b) += V(h0)^T P(b,h0) || P(b,h1)     6: O(a), O(b) += V(h1)^T P(.,h1)
     // K fragments of a key half serve both blocks, V^T fragments likewise.  SCHED 1 pins each phase's issue as
     // {1 MFMA, VPOLY / 4 VALU} groups; SCHED 0 only fences the phases.
-    auto tile2 = [&](int kt, int stage, auto masked_tag) {
+    auto tile2 = [&](int kt, int stage, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int VPOLY = (P == 2 ? 16 : 0) + 16 + 8 + (MASKED ? 32 : 0);
         const int KI = stage * STAGE, VI = KI + NP * KIMG, k0 = kt * 64;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) oacc[qb_][dt] = mfma32_parts<NP, NPP>(vf[s][dt], pf[s], oacc[qb_][dt]);
         };
-        auto group = [&](auto id_tag) {
+        auto group = [&](auto id_tag) __attribute__((always_inline)) {
             constexpr int ID = decltype(id_tag)::value;
             if constexpr (SCHED == 1) {
 #pragma unroll
@@ -317,13 +317,13 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
         pv(0, vf1, pa1);
         pv(B1, vf1, pb1);
     };
-    auto tile = [&](int kt, int stage, auto masked_tag) {
+    auto tile = [&](int kt, int stage, auto masked_tag) __attribute__((always_inline)) {
         if constexpr (QB == 2) tile2(kt, stage, masked_tag);
         else tile1(kt, stage, masked_tag);
     };
     // staging half of an iteration: tile kt+1 goes to the other stage (last read before the previous barrier), tile kt+2
     // is requested
-    auto advance = [&](int kt) {
+    auto advance = [&](int kt) __attribute__((always_inline)) {
         if (kt + 1 < nkt) {
             commit((kt & 1) ^ 1);
             if (kt + 2 < nkt) request(kt + 2);
@@ -424,7 +424,11 @@ static int launch_quad32_t(const Quad32Params& prm, hipStream_t stream) {
 }
 template <int P, typename TIN>
 static int launch_quad32_d(const Quad32Params& prm, hipStream_t stream) {
-    return prm.D <= 64 ? launch_quad32_t<64, P, TIN>(prm, stream) : launch_quad32_t<128, P, TIN>(prm, stream);
+    if constexpr (InTraits<TIN>::NP == 2) {          // two-part operands stop at D = 64 (quad32_supported)
+        return prm.D <= 64 ? launch_quad32_t<64, P, TIN>(prm, stream) : FASTMAX_E_BAD_SHAPE;
+    } else {
+        return prm.D <= 64 ? launch_quad32_t<64, P, TIN>(prm, stream) : launch_quad32_t<128, P, TIN>(prm, stream);
+    }
 }
 template <typename TIN>
 static int launch_quad32_p(const Quad32Params& prm, int p, hipStream_t stream) {

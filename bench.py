@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--accum", type=int, default=2, help="dp_step: gradient accumulation iterations per optimizer step and rank")
     ap.add_argument("--toy", action="store_true", help="dp_step: CPU stand-in model (rehearsal of the multi-rank control flow)")
     ap.add_argument("--graph", action="store_true", help="dp_step: replay each micro-batch (forward + backward) as one captured HIP graph")
+    ap.add_argument("--allow-variant", action="store_true",
+                    help="A/B runs: time a non-default headline kernel (tuning key mfma_variant != 200); the line is marked "
+                         "\"headline\": false.  Without it bench.py refuses such a run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -150,8 +153,27 @@ def dp_step_main(args, dev, rank, world, multi, json_fd):
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`--gpus N` (N > 1) without a torch.distributed.run environment: start the N ranks the way the driver does, as child
+    processes of THIS process -- before anything here has touched the GPU -- and exit with their status.  Rank 0 of the children
+    prints the one JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     # stdout carries exactly ONE JSON line (rank 0).  Libraries write there too -- the image exports NCCL_DEBUG=VERSION and RCCL
     # prints a five-line banner (and its warnings) on stdout, NCCL_DEBUG_FILE notwithstanding -- so file descriptor 1 points
     # at stderr for the whole run and the JSON line goes to the saved descriptor.
@@ -164,8 +186,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong number of GPUs")
     cpu_toy = args.workload == "dp_step" and args.toy
     if not torch.cuda.is_available() and not cpu_toy:
         raise SystemExit("bench.py needs an MI355X: the fastmax operator has no CPU fallback")
@@ -196,8 +218,15 @@ def main():
     from attention_mechanisms.fastmax import fastmax
     from attention_mechanisms.fastmax_hack import fastmax_hack
     from fastmax_experiments_amd import _lib, ops
-    _lib.lib()
+    L = _lib.lib()
     ops.set_forced_path({"auto": 0, "quadratic": 1, "recurrent": 2, "mfma": 3}[args.path])
+    tune_state = {k: L.fastmax_hip_tune_get(k.encode()) for k in ("mfma_variant", "bf16_kernel", "gemm_sched", "gemm_group_m", "gemm_xcd")}
+    tune_state["build_flags"] = L.fastmax_hip_build_flags()           # bit 0: built with the timing-only (wrong-result) ablations
+    tune_state["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("FASTMAX_")}
+    default_kernel = tune_state["mfma_variant"] == 200 and tune_state["build_flags"] == 0
+    if not default_kernel and not args.allow_variant:
+        raise SystemExit(f"bench.py: the headline kernel is not the default one (mfma_variant={tune_state['mfma_variant']}, "
+                         f"build_flags={tune_state['build_flags']}); pass --allow-variant for an A/B run")
 
     B, H, N, D = args.batch, args.heads, args.seq, args.dim
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
@@ -219,12 +248,15 @@ def main():
         return o
 
     path = _lib.PATH_NAMES.get(ops.selected_path(q, k, args.p, True), "?")
+    launches = {"n": 0}                                   # steps issued so far (each is one launch of the dominant kernel)
 
     def protocol():
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs.
         -> (elapsed seconds, MAX over ranks; mean device-side step duration in ms from HIP events on the launch stream)"""
         for _ in range(args.warmup):
             step()
+        launches["n"] += args.warmup
+        launches["before_timed"] = launches["n"]
         torch.cuda.synchronize(dev)
         if multi:
             dist.barrier()
@@ -244,7 +276,9 @@ def main():
             t = torch.tensor([el], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps
+        launches["n"] += args.steps
+        per = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+        return el, sum(per) / args.steps, per
 
     # From an idle device the chip runs the first launches at boost clock, then its power controller pulls the clock down and
     # lets it recover over ~30 ms (profiles/r02_transient.md: the same memory traffic without the matrix instructions shows
@@ -259,8 +293,9 @@ def main():
         while time.perf_counter() < t_end:
             for _ in range(16):
                 step()
+            launches["n"] += 16
             torch.cuda.synchronize(dev)
-    elapsed, kernel_ms = protocol()
+    elapsed, kernel_ms, per_launch = protocol()
 
     if rank == 0:
         es = {"f32": 4, "bf16": 2, "f16": 2}[args.dtype]
@@ -284,6 +319,10 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            # every launch of the step before the first timed one: the W warm-up steps of the timed pass and, ahead of them, the
+            # from-idle pass ("cold_start": W + K launches) and the --precondition-ms of back-to-back steps
+            "effective_warmup_launches": launches["before_timed"],
+            "headline": bool(default_kernel),
             "config": {"workload": f"{args.op} p={args.p} masked {args.mode}, (B,H,N,D)=({B},{H},{N},{D}) per GPU, "
                                    f"q,k,v~N(0,1) seed=rank, {args.dtype} I/O, fp32 accumulate",
                        "B_per_gpu": B, "H": H, "N": N, "D": D, "global_batch": B * world,
@@ -291,16 +330,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kernel_ms, 4),
+                         "per_launch_ms": {"min": round(min(per_launch), 4), "median": round(sorted(per_launch)[len(per_launch) // 2], 4),
+                                           "max": round(max(per_launch), 4), "n": len(per_launch)},
                          "head_tokens_per_s": round(B * H * N / (kernel_ms * 1e-3), 1)},
         }
         line["precondition_ms"] = args.precondition_ms
+        line["tune_state"] = tune_state
         if cold is not None:
-            c_el, c_ms = cold
+            c_el, c_ms, c_per = cold
             line["cold_start"] = {
                 "note": "the same W warm-up + K timed steps started from an idle device, before the preconditioning: the chip's "
                         "power controller dips the clock for ~30 ms after a start from idle (profiles/r02_transient.md)",
                 "value": round(world * B * N * args.steps / c_el, 1), "ms_per_step": round(c_el * 1e3 / args.steps, 4),
-                "kernel_ms": round(c_ms, 4), "achieved": round(alg_bytes / (c_ms * 1e-3) / 1e9, 1),
+                "effective_warmup_launches": args.warmup,
+                "kernel_ms": round(c_ms, 4), "per_launch_ms": {"min": round(min(c_per), 4), "max": round(max(c_per), 4)},
+                "achieved": round(alg_bytes / (c_ms * 1e-3) / 1e9, 1),
                 "frac": round(alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -31,7 +31,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s",
            "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed",
            "fastmax_hip_lmhead_ce_workspace", "fastmax_hip_lmhead_ce_forward", "fastmax_hip_lmhead_ce_backward",
-           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope"]
+           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags"]
 
 
 class Problem(ctypes.Structure):
@@ -60,6 +60,10 @@ def lib():
     pp = ctypes.POINTER(Problem)
     L.fastmax_hip_tune.argtypes = [ctypes.c_char_p, ci]
     L.fastmax_hip_tune.restype = ci
+    L.fastmax_hip_tune_get.argtypes = [ctypes.c_char_p]
+    L.fastmax_hip_tune_get.restype = ci
+    L.fastmax_hip_build_flags.argtypes = []
+    L.fastmax_hip_build_flags.restype = ci
     L.fastmax_hip_forward_workspace.argtypes = [pp]
     L.fastmax_hip_forward_workspace.restype = sz
     L.fastmax_hip_forward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, sz, vp]
@@ -149,7 +153,7 @@ def lib():
     L.fastmax_hip_select_path.restype = ci
     L.fastmax_hip_error_string.argtypes = [ci]
     L.fastmax_hip_error_string.restype = ctypes.c_char_p
-    if L.fastmax_hip_abi_version() != 7:
+    if L.fastmax_hip_abi_version() != 8:
         raise RuntimeError("libfastmax_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -1,6 +1,7 @@
 // extern "C" entry points of libfastmax_hip.so (see include/fastmax_hip.h) + path selection.
 #include "fastmax_common.h"
 
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 
@@ -47,6 +48,9 @@ bool aligned16(const void* ptr, const int64_t* s, int dtype) {
 }  // namespace
 
 namespace fastmax {
+// "mfma_variant" numbers whose kernels leave out matrix instructions or memory passes (timing-only, wrong results): they exist
+// in -DFASTMAX_ABLATIONS builds only
+static bool wrong_result_variant(int v) { return v == 119 || v == 129 || v == 219 || v == 201 || (v >= 204 && v <= 209); }
 namespace {
 struct TuneEntry { const char* name; const char* env; int value; };
 TuneEntry g_tune[TUNE_COUNT] = {
@@ -64,6 +68,9 @@ void tune_load() {
         if (!e) continue;
         if (i == TUNE_BF16_KERNEL) g_tune[i].value = e[0] == 'g' ? 0 : 1;
         else g_tune[i].value = atoi(e);
+#ifndef FASTMAX_ABLATIONS
+        if (i == TUNE_MFMA_VARIANT && wrong_result_variant(g_tune[i].value)) g_tune[i].value = 200;   // not in this build
+#endif
     }
     g_tune_loaded = true;
 }
@@ -75,8 +82,20 @@ int tune_get(int key) {
 int tune_set(const char* name, int value) {
     tune_load();
     for (int i = 0; i < TUNE_COUNT; ++i)
-        if (!strcmp(name, g_tune[i].name)) { g_tune[i].value = value; return FASTMAX_OK; }
+        if (!strcmp(name, g_tune[i].name)) {
+#ifndef FASTMAX_ABLATIONS
+            if (i == TUNE_MFMA_VARIANT && wrong_result_variant(value)) return FASTMAX_E_BAD_SHAPE;
+#endif
+            g_tune[i].value = value;
+            return FASTMAX_OK;
+        }
     return FASTMAX_E_BAD_SHAPE;
+}
+int tune_get_by_name(const char* name) {
+    tune_load();
+    for (int i = 0; i < TUNE_COUNT; ++i)
+        if (!strcmp(name, g_tune[i].name)) return g_tune[i].value;
+    return INT_MIN;
 }
 }  // namespace fastmax
 
@@ -85,6 +104,14 @@ extern "C" {
 int fastmax_hip_abi_version(void) { return FASTMAX_ABI_VERSION; }
 
 int fastmax_hip_tune(const char* name, int value) { return name ? tune_set(name, value) : FASTMAX_E_NULL; }
+int fastmax_hip_tune_get(const char* name) { return name ? tune_get_by_name(name) : INT_MIN; }
+int fastmax_hip_build_flags(void) {
+#ifdef FASTMAX_ABLATIONS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char* fastmax_hip_error_string(int code) {
     switch (code) {

@@ -107,6 +107,7 @@ bool mfma_p1_v2_supported(const FwdArgs& a);
 enum TuneKey { TUNE_MFMA_VARIANT = 0, TUNE_BF16_KERNEL = 1, TUNE_GEMM_SCHED = 2, TUNE_GEMM_GROUP_M = 3, TUNE_GEMM_XCD = 4, TUNE_COUNT };
 int tune_get(int key);
 int tune_set(const char* name, int value);
+int tune_get_by_name(const char* name);
 bool mfma_p1_supported(const fastmax_problem& p);
 size_t mfma_p1_workspace(const fastmax_problem& p);
 int launch_fwd_mfma_gen(const FwdArgs& a, const float* qscale, const float* kscale);

@@ -491,9 +491,11 @@ int launch_fwd_mfma_p1(const FwdArgs& a) {
     switch (variant) {
         case 110: return launch_variant<1, 1, 0>(prm, nb, a.stream);     // <prefetch><staged stores><batched schedule>
         case 210: return launch_variant<2, 1, 0>(prm, nb, a.stream);
-        case 129: return launch_variant<1, 2, 9>(prm, nb, a.stream);
-        case 119: return launch_variant<1, 1, 9>(prm, nb, a.stream);     // memory-pattern ablation (timing only)
+#ifdef FASTMAX_ABLATIONS
+        case 129: return launch_variant<1, 2, 9>(prm, nb, a.stream);     // memory-pattern ablations: timing only, WRONG RESULTS
+        case 119: return launch_variant<1, 1, 9>(prm, nb, a.stream);
         case 219: return launch_variant<2, 1, 9>(prm, nb, a.stream);
+#endif
         case 111: return launch_variant<1, 1, 1>(prm, nb, a.stream);
         default: return launch_variant<1, 2, 1>(prm, nb, a.stream);      // 121: batched schedule, staged non-temporal stores
     }

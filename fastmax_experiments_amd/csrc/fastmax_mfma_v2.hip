@@ -444,8 +444,9 @@ int launch_fwd_mfma_p1_v2(const FwdArgs& a, int ablation) {
                      reinterpret_cast<const float*>(a.workspace), plan.nseg, plan.cps};
     const int nb = a.prob.B * a.prob.H * plan.nseg;
     const bool ragged = (a.prob.Nq & 63) != 0;
-    switch (ablation) {                                              // memory-only ablations (timing only)
-        case 1: return launch_v2_variant<1, true>(prm, nb, a.stream);
+#ifdef FASTMAX_ABLATIONS
+    switch (ablation) {                                              // timing-only ablations: WRONG RESULTS, ablation builds only
+        case 1: return launch_v2_variant<1, true>(prm, nb, a.stream);        // memory passes only
         case 6: return launch_v2_variant<2, true>(prm, nb, a.stream);
         case 7: return launch_v2_variant<3, true>(prm, nb, a.stream);
         case 8: return launch_v2_variant<4, true>(prm, nb, a.stream);
@@ -453,6 +454,9 @@ int launch_fwd_mfma_p1_v2(const FwdArgs& a, int ablation) {
         case 5: return launch_v2_variant<0, true, 0>(prm, nb, a.stream);      // no matrix instructions
         default: break;
     }
+#else
+    (void)ablation;
+#endif
     return ragged ? launch_v2_variant<0, true>(prm, nb, a.stream) : launch_v2_variant<0, false>(prm, nb, a.stream);
 }
 

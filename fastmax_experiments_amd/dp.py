@@ -153,6 +153,11 @@ class DataParallelStepper:
         outside the graph.  Needs static shapes (every micro-batch like `sample_batch`) and a step without host
         synchronisation -- which the HIP path is (workspaces come from the caching allocator, scalars stay on the device)."""
         dev = self.bucket.flat.device
+        if not all(self.bucket._aliased):
+            # a parameter whose dtype differs from the bucket's gets a separate .grad tensor that the recorded AccumulateGrad
+            # would keep writing to after gather() has dropped it (and the warm-up gradients would enter the first step)
+            raise RuntimeError("graph capture needs every trainable parameter in the bucket's dtype "
+                               f"({self.bucket.dtype}): its .grad must be a view of the bucket")
         if dev.type != "cuda":
             raise RuntimeError("graph capture needs a HIP device")
         self._static = tuple(t.clone() for t in sample_batch)
@@ -180,7 +185,7 @@ class DataParallelStepper:
             for dst, src in zip(self._static, batch):
                 dst.copy_(src)
             self._graph.replay()
-            loss = self._static_loss
+            loss = self._static_loss.detach().clone()      # the recorded tensor is overwritten by the next replay
         else:
             loss = self.loss_fn(self.model, batch)
             (loss / self.accum).backward()

@@ -15,6 +15,7 @@ Fused forward (csrc/nf4_lora.hip):  y = x deq(W)^T + bias + (dropout(x) A^T) (sc
 """
 import ctypes
 import os
+import weakref
 import math
 from typing import Any, Tuple, Union
 
@@ -536,13 +537,29 @@ def gemm_rope_supported(N, K, M, T, G, qpk, hs, rope_n) -> bool:
             and rope_n % 16 == 0 and K % 64 == 0 and M % T == 0 and ((M + 255) // 256) * ((N + 255) // 256) > 128)
 
 
+_frozen_wt = weakref.WeakKeyDictionary()
+
+
+def _frozen_transpose(owner: nn.Module) -> torch.Tensor:
+    """W^T (K, N) of a dense FROZEN base layer for the dx product, built once per layer (and again if the weight is written or
+    replaced: the entry carries the parameter's identity, version counter and device) instead of once per layer per backward
+    pass; it lives as long as the layer does.  A second N K 2 bytes per dense-base layer, on a 288 GB part."""
+    w = owner.weight
+    tag = (id(w), w._version, w.data_ptr(), w.device)
+    hit = _frozen_wt.get(owner)
+    if hit is None or hit[0] != tag:
+        hit = (tag, w.detach().t().contiguous())
+        _frozen_wt[owner] = hit
+    return hit[1]
+
+
 class _QLoRAGemmFn(torch.autograd.Function):
     """y = x deq(W)^T + bias + (x A^T) eb^T with every product in libfastmax_hip.so (lit_gpt/lora.py:170-177, 419-433 and
     their autograd mirror, without dropout): the frozen product and dx by the 256 x 256-tile GEMM with the LoRA branch as
     its last step, x A^T / dy eb by lora_down, dA / dB by lora_tn."""
 
     @staticmethod
-    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused, rope=None):
+    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused, rope=None, owner=None):
         """rope = (cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand): the product is an attention sub-layer's qkv
         projection and leaves the kernel as (q, k, v) -- de-interleaved and rotated, in the layout of ops.RopeQKVSplit's
         `expand` mode 0 (k, v at their G heads; also mode 1 when qpk == 1), 3 or 4 (stride-0 group views) -- instead of y"""
@@ -559,6 +576,7 @@ class _QLoRAGemmFn(torch.autograd.Function):
         ctx.dims = (N, K, R, A.dtype)
         ctx.rope = rope
         ctx.dense_base = wdense if wq is None else None           # a dense frozen base: its own weight serves dx
+        ctx.dense_owner = owner if wq is None else None           # ... and its layer keeps the transposed copy
         if rope is not None:
             cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand = rope
             w = wdense if wdense is not None else _dense_weight(wq, scales, N, K)
@@ -591,13 +609,16 @@ class _QLoRAGemmFn(torch.autograd.Function):
             d_ea, d_eat = lora_down(dy, ebt)
         if ctx.needs_input_grad[0]:
             # dx = dy W + d_ea abt: the GEMM over n with W^T as its weight operand and the LoRA step (d_ea, abt^T)
-            wt = ctx.dense_base.t().contiguous() if ctx.dense_base is not None else _dense_weight_t(wq, ctx.scales, N, K)
+            if ctx.dense_base is None:
+                wt = _dense_weight_t(wq, ctx.scales, N, K)
+            else:
+                wt = _frozen_transpose(ctx.dense_owner) if ctx.dense_owner is not None else ctx.dense_base.t().contiguous()
             dx = hip_gemm(dy, wt, None, None, d_ea, abt.t().contiguous(), K)
         if ctx.needs_input_grad[1]:
             dA = lora_tn(d_eat, x2, R, a_dt)
         if ctx.needs_input_grad[2]:
             d_ebt = lora_tn(eat, dy, dtype=torch.bfloat16)
-        return dx, dA, d_ebt, None, None, None, None, None, None, None, None
+        return dx, dA, d_ebt, None, None, None, None, None, None, None, None, None
 
 
 class _QLoRAThinFn(torch.autograd.Function):
@@ -662,7 +683,7 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None):
         bias = bias.float()
     if not isinstance(base, NF4Linear):
         # a dense bf16 frozen base (LoRA without quantisation, lit_gpt/lora.py:170-177): the same tile GEMM on the weight itself
-        y = _QLoRAGemmFn.apply(x2, A, ebt, None, None, bias, N, K, base.weight.data, False, rope)
+        y = _QLoRAGemmFn.apply(x2, A, ebt, None, None, bias, N, K, base.weight.data, False, rope, base)
         return y if rope is not None else y.reshape(*x.shape[:-1], N)
     scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
@@ -816,8 +837,11 @@ class LoRALinear(LoRALayer):
         no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
         M = x.numel() // x.shape[-1]
         w = lin.weight
+        # the tile GEMM's autograd function treats the base (weight AND bias) as frozen data: a trainable bias
+        # (mark_only_lora_as_trainable(bias="all" / "lora_only"), lit_gpt/lora.py:436-461) stays on the tensor-op route
+        frozen_bias = lin.bias is None or not lin.bias.requires_grad
         return (no_dropout and LORA_THIN and QLORA_ROUTE == "gemm" and x.device.type == "cuda" and x.dtype == torch.bfloat16
-                and w.dtype == torch.bfloat16 and not w.requires_grad and w.is_contiguous() and M >= DENSE_M
+                and w.dtype == torch.bfloat16 and not w.requires_grad and frozen_bias and w.is_contiguous() and M >= DENSE_M
                 and self.lora_A.shape[0] <= RANK_PAD and lin.in_features % 128 == 0 and lin.out_features % 64 == 0)
 
 
@@ -906,10 +930,20 @@ class LoRAQKVLinear(LoRALinear):
         return self.r > 0 and any(self.enable_lora) and not self.merged
 
 
-def mark_only_lora_as_trainable(model: nn.Module) -> None:
-    """lit_gpt/lora.py:450-452."""
-    for n, p in model.named_parameters():
-        p.requires_grad = "lora_" in n
+def mark_only_lora_as_trainable(model: nn.Module, bias: str = "none") -> None:
+    """lit_gpt/lora.py:436-461: everything that is not a LoRA matrix is frozen; `bias` then thaws bias vectors again --
+    "none": no bias trains, "all": every parameter with "bias" in its name, "lora_only": the `bias` attribute of LoRA layers
+    that have one.  Anything else raises NotImplementedError, as the reference does."""
+    if bias not in ("none", "all", "lora_only"):
+        raise NotImplementedError(f"bias={bias!r}")
+    for name, p in model.named_parameters():
+        if "lora_" not in name:
+            p.requires_grad = bias == "all" and "bias" in name
+    if bias == "lora_only":
+        for m in model.modules():
+            own = getattr(m, "bias", None) if isinstance(m, LoRALayer) else None
+            if own is not None:
+                own.requires_grad = True
 
 
 def lora_filter(key: str, value: Any) -> bool:

@@ -106,7 +106,10 @@ def chunked_cross_entropy(logits: Union[torch.Tensor, List[torch.Tensor]], targe
         rows = cross_entropy_rows(logits, targets, ignore_index)
         vocab = logits.size(-1)
     non_masked_elems = scored_rows(targets, vocab, ignore_index).sum()
-    return rows.sum() / non_masked_elems.clamp(min=1)
+    if chunk_size == 0:
+        # the reference hands these branches to cross_entropy's own mean (utils.py:245, 262): NaN when no target is scored
+        return rows.sum() / non_masked_elems
+    return rows.sum() / non_masked_elems.clamp(min=1)                       # utils.py:256, 272: max(1, non_masked_elems)
 
 
 def _kept_backward(ctx, grad_out):

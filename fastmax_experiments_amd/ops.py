@@ -227,6 +227,11 @@ _ROPE_F32 = {}
 def _rope_tables_f32(cos, sin, T, n_elem):
     """the kernel's exact float32 copies of the first T rows of the rope cache; every layer of a step asks for the same
     tables, so the last conversion is kept (keyed by storage, version and shape of the cache tensors)"""
+    if cos.is_cuda and torch.cuda.is_current_stream_capturing():
+        # a recorded HIP graph keeps reading these tables on every replay: allocate them inside the capture, so that they
+        # live in the graph's own memory pool (an entry of the one-slot cache below is freed by the next eager call with
+        # another sequence length, rope cache or model)
+        return cos[:T, :n_elem].float().contiguous(), sin[:T, :n_elem].float().contiguous()
     key = (cos.data_ptr(), sin.data_ptr(), cos._version, sin._version, tuple(cos.shape), cos.dtype, str(cos.device), T, n_elem)
     hit = _ROPE_F32.get("last")
     if hit is not None and hit[0] == key:

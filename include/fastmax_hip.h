@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 7   /* 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -59,6 +59,12 @@ enum fastmax_path {
  * forward kernel generation / schedule), "bf16_kernel" (1 = all-MFMA bf16 scan, 0 = generic).  Host-only, not stream-ordered:
  * call it between launches.  Returns 0, or FASTMAX_E_BAD_SHAPE for an unknown key. */
 int fastmax_hip_tune(const char* name, int value);
+/* Current value of a tuning key (so that a benchmark line can record the state it was measured in); INT_MIN for an unknown
+ * key.  fastmax_hip_build_flags(): bit 0 = the library was built with -DFASTMAX_ABLATIONS, i.e. it contains the timing-only
+ * kernel variants whose RESULTS ARE WRONG (matrix instructions or memory passes removed); a production build has none and
+ * fastmax_hip_tune refuses their "mfma_variant" numbers with FASTMAX_E_BAD_SHAPE. */
+int fastmax_hip_tune_get(const char* name);
+int fastmax_hip_build_flags(void);
 
 typedef struct fastmax_problem {
     int B, H, Nq, Nk, D;

@@ -28,9 +28,22 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.fastmax_hip_abi_version() == 7
+    assert lib.fastmax_hip_abi_version() == 8
     assert b"p should be 1 or 2" in lib.fastmax_hip_error_string(-1)
     assert lib.fastmax_hip_error_string(0) == b"ok"
+
+
+def test_tuning_state_is_readable_and_wrong_result_variants_are_not_in_the_production_build(lib):
+    """the bench line records the tune state; the timing-only kernel variants (matrix instructions / memory passes removed) exist
+    only in -DFASTMAX_ABLATIONS builds"""
+    assert lib.fastmax_hip_build_flags() == 0
+    assert lib.fastmax_hip_tune_get(b"mfma_variant") == 200
+    assert lib.fastmax_hip_tune_get(b"no_such_key") == -2 ** 31
+    for v in (201, 204, 205, 206, 209, 119, 129, 219):
+        assert lib.fastmax_hip_tune(b"mfma_variant", v) == -2
+        assert lib.fastmax_hip_tune_get(b"mfma_variant") == 200
+    assert lib.fastmax_hip_tune(b"mfma_variant", 121) == 0 and lib.fastmax_hip_tune_get(b"mfma_variant") == 121
+    assert lib.fastmax_hip_tune(b"mfma_variant", 200) == 0
 
 
 def test_problem_validation_without_gpu(lib):

@@ -108,6 +108,20 @@ def test_mixed_dtype_bucket():
     assert m.lora_A.grad.dtype == torch.bfloat16 and float(b.flat.abs().sum()) > 0
 
 
+def test_graph_capture_refuses_parameters_outside_the_bucket_dtype():
+    """capture() records AccumulateGrad nodes that write each parameter's .grad: that only stays valid when every .grad IS a
+    view of the bucket (a bf16 parameter in an fp32 bucket gets a tensor of its own, which gather() drops)"""
+    from fastmax_experiments_amd.dp import DataParallelStepper, TrainArgs
+    m = TinyLoRA()
+    for n, p in m.named_parameters():
+        p.requires_grad = "lora_" in n
+    m.lora_A.data = m.lora_A.data.to(torch.bfloat16)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.1)
+    st = DataParallelStepper(m, opt, TrainArgs(global_batch_size=4, micro_batch_size=4), _loss, bucket_dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="bucket's dtype"):
+        st.capture((torch.zeros(4, 16), torch.zeros(4, 16)))
+
+
 def test_accumulation_iters_follow_reference_args():
     from fastmax_experiments_amd import dp
     t = dp.TrainArgs(global_batch_size=64, micro_batch_size=4)
@@ -144,3 +158,21 @@ def test_bench_dp_step_mode_two_ranks_over_gloo():
     assert two["allreduce"]["backend"] == "gloo" and two["allreduce"]["per_step"] == 1
     assert two["allreduce"]["bucket_bytes"] == one["allreduce"]["bucket_bytes"] == 4 * two["trainable_params"]
     assert two["value"] > 0 and two["ms_per_step"] > 0 and two["last_loss"] == two["last_loss"]
+
+
+def test_bench_gpus_without_a_launcher_spawns_its_ranks_or_fails():
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no WORLD_SIZE) must not quietly run one rank and report
+    n_gpus 1: it starts the N ranks itself (before touching a GPU) and passes their one JSON line through; a WORLD_SIZE that
+    disagrees with --gpus exits non-zero."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "dp_step", "--toy", "--steps", "2", "--warmup", "1",
+           "--seq", "16"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

@@ -212,3 +212,21 @@ def test_nf4_double_quant_layer_state_and_copies():
     before = lay.linear.dequantize()
     lay.merge()
     assert lay.linear.double_quant and float((lay.linear.dequantize() - before - lay.get_lora_AB()).abs().max()) < 0.2 * float(before.abs().max())
+
+
+def test_mark_only_lora_as_trainable_bias_modes():
+    """lit_gpt/lora.py:436-461: "none" freezes every bias, "all" thaws every parameter named *bias*, "lora_only" thaws the
+    `bias` attribute of LoRA layers (LoRALinear keeps its bias inside `.linear`, so -- as in the reference -- nothing thaws),
+    anything else raises NotImplementedError"""
+    from fastmax_experiments_amd import lora
+    m = torch.nn.Sequential(lora.LoRALinear(8, 8, r=2, bias=True), torch.nn.Linear(8, 4, bias=True))
+    flags = lambda: {n: p.requires_grad for n, p in m.named_parameters()}
+    lora.mark_only_lora_as_trainable(m)
+    assert flags() == {"0.lora_A": True, "0.lora_B": True, "0.linear.weight": False, "0.linear.bias": False, "1.weight": False,
+                       "1.bias": False}
+    lora.mark_only_lora_as_trainable(m, bias="all")
+    assert flags()["0.linear.bias"] and flags()["1.bias"] and not flags()["1.weight"] and flags()["0.lora_A"]
+    lora.mark_only_lora_as_trainable(m, bias="lora_only")
+    assert not flags()["0.linear.bias"] and not flags()["1.bias"]
+    with pytest.raises(NotImplementedError):
+        lora.mark_only_lora_as_trainable(m, bias="some")

@@ -461,3 +461,34 @@ def test_dense_base_lora_layers_on_the_tile_gemm(kind, monkeypatch):
         layer.lora_A.grad = layer.lora_B.grad = None
     for got, want in zip(*res):
         assert float((got - want).abs().max()) <= 3e-2 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_dense_base_with_a_trainable_bias_keeps_its_gradient():
+    """mark_only_lora_as_trainable(bias="all") (lit_gpt/lora.py:436-461): the tile GEMM's autograd function treats the base as
+    frozen data, so a layer whose bias trains must stay on the tensor-op route and deliver d(bias); the transposed copy of a
+    frozen dense weight is built once per layer and rebuilt when the weight is written"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(5)
+    layer = lora.LoRALinear(256, 384, r=8, lora_alpha=16, bias=True).to(torch.bfloat16).cuda()
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    lora.mark_only_lora_as_trainable(layer, bias="all")
+    x = torch.randn(2, 1500, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    assert layer.linear.bias.requires_grad and not layer._dense_base_on_tile_gemm(x)
+    layer(x).sum().backward()
+    assert layer.linear.bias.grad is not None and float(layer.linear.bias.grad.float().abs().sum()) > 0
+    # frozen bias: the tile GEMM route, with W^T cached per layer
+    lora.mark_only_lora_as_trainable(layer)
+    assert layer._dense_base_on_tile_gemm(x)
+    for _ in range(2):
+        x.grad = None
+        layer(x).sum().backward()
+    wt = lora._frozen_wt[layer.linear][1]
+    assert torch.equal(wt, layer.linear.weight.detach().t())
+    first = x.grad.clone()
+    with torch.no_grad():
+        layer.linear.weight.mul_(0.5)                                # written in place: the version counter moves
+    x.grad = None
+    layer(x).sum().backward()
+    assert lora._frozen_wt[layer.linear][1] is not wt
+    assert not torch.equal(x.grad, first)

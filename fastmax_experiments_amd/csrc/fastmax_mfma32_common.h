@@ -130,37 +130,6 @@ __device__ __forceinline__ Frag<InTraits<TIN>::NP> load_q_frag_scaled(const TIN*
     return f;
 }
 
-// 64-row tiles of one (b,h) slab of a (N, D) tensor through a buffer descriptor (staging map: row = srow + ps*RPP,
-// 16-byte piece scol).  The record count is the slab's own byte range, so rows past the tensor read as zero in
-// hardware (the range check covers the VGPR offset, which is why the tile offset is added there and not passed as the
-// scalar offset); lanes of a padded head column carry an offset that is always out of range.  A request costs NPASS
-// loads + NPASS integer adds, no compares.  The caller guarantees the slab spans less than 2 GiB (quad32_span_ok).
-template <typename TIN, int NPASS, int RPP>
-struct BufTileLoader {
-    __amdgpu_buffer_rsrc_t rs;
-    int voff[NPASS];
-    int tile_bytes;
-    __device__ __forceinline__ BufTileLoader(const TIN* base, int64_t sn, int nrows, int D, int srow, int scol) {
-        constexpr int EPL = InTraits<TIN>::EPL;
-        const int row_bytes = (int)sn * (int)sizeof(TIN);
-        const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(base), 0, nrec, 0x00020000);
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-            voff[ps] = scol * EPL < D ? (srow + ps * RPP) * row_bytes + scol * 16 : (int)0x80000000;
-        tile_bytes = 64 * row_bytes;
-    }
-    __device__ __forceinline__ void load(int tile, u32x4 (&r)[NPASS]) const {
-        const int t = tile * tile_bytes;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ps] + t, 0, 0);
-    }
-};
-// host side: the byte range of one (b,h) slab fits the 31-bit offsets above
-inline bool quad32_span_ok(int64_t sn, int nrows, int D, int elem_bytes) {
-    return sn >= 0 && ((int64_t)(nrows > 0 ? nrows - 1 : 0) * sn + D) * elem_bytes < (int64_t)0x40000000;
-}
-
 // Write a wave's transposed accumulator tiles (acc[dt][i]: column 32dt + row(i) of tensor row first_row + (lane&31))
 // times `scale` (per lane = per tensor row) as whole row segments, 32 rows x 32 columns at a time through a
 // wave-private 4 KiB LDS area.  row0_elem = element index of tensor row 0 of this (b,h) slab / D.

@@ -54,10 +54,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_bf16_kernel
     const float invD = 1.0f / (float)D;
     const int srow = tid / COLS, scol = tid % COLS;
     const bool colok = scol * EPL < D;
+    const float qsc_c = colok ? qsc : 0.f, ksc_c = colok ? ksc : 0.f;
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS];
-    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
-        vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    // buffer-descriptor loads (non-temporal): rows past N and padded head columns arrive as zeros, no address arithmetic
+    const BufTileLoader<TIN, NPASS, RPP, 2> qload(qb, prm.qs.sn, N, D, srow, scol), kload(kb, prm.ks.sn, N, D, srow, scol),
+        vload(vb, prm.vs.sn, N, D, srow, scol);
     auto issue = [&](int c) {
         qload.load(c, rq);
         kload.load(c, rk);
@@ -143,12 +145,13 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void fwd_p1_mfma_bf16_kernel
                 float sq = 0.f, sk = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { sq += xq[e]; sk += xk[e]; }
-                const float mq = rowgroup_allsum<COLS>(sq) * invD, mk = rowgroup_allsum<COLS>(sk) * invD;
-                const bool live = colok && (n0 + row < N);
+                // (x - mean) * scale as one fma per element; a row past N was loaded as zeros (mean 0 -> 0), a padded head
+                // column has its scale zeroed (qsc_c / ksc_c)
+                const float nmq = -rowgroup_allsum_dpp<COLS>(sq) * invD * qsc_c, nmk = -rowgroup_allsum_dpp<COLS>(sk) * invD * ksc_c;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    xq[e] = live ? (xq[e] - mq) * qsc : 0.f;
-                    xk[e] = live ? (xk[e] - mk) * ksc : 0.f;
+                    xq[e] = fmaf(xq[e], qsc_c, nmq);
+                    xk[e] = fmaf(xk[e], ksc_c, nmk);
                 }
                 stage_floats<DP, EPL, 1>(smem, QI, row, scol, xq);
                 stage_floats<DP, EPL, 1>(smem, KI, row, scol, xk);
@@ -280,10 +283,12 @@ __global__ __launch_bounds__(512, 2) void fwd_p1_mfma_bf16_d128_kernel(Bf16Param
     const float invD = 1.0f / (float)D;
     const int srow = tid / COLS, scol = tid % COLS;
     const bool colok = scol * EPL < D;
+    const float qsc_c = colok ? qsc : 0.f, ksc_c = colok ? ksc : 0.f;
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS];
-    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
-        vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    // buffer-descriptor loads (non-temporal): rows past N and padded head columns arrive as zeros, no address arithmetic
+    const BufTileLoader<TIN, NPASS, RPP, 2> qload(qb, prm.qs.sn, N, D, srow, scol), kload(kb, prm.ks.sn, N, D, srow, scol),
+        vload(vb, prm.vs.sn, N, D, srow, scol);
     auto issue = [&](int c) {
         qload.load(c, rq);
         kload.load(c, rk);
@@ -343,12 +348,13 @@ __global__ __launch_bounds__(512, 2) void fwd_p1_mfma_bf16_d128_kernel(Bf16Param
                 float sq = 0.f, sk = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { sq += xq[e]; sk += xk[e]; }
-                const float mq = rowgroup_allsum<COLS>(sq) * invD, mk = rowgroup_allsum<COLS>(sk) * invD;
-                const bool live = colok && (n0 + row < N);
+                // (x - mean) * scale as one fma per element; a row past N was loaded as zeros (mean 0 -> 0), a padded head
+                // column has its scale zeroed (qsc_c / ksc_c)
+                const float nmq = -rowgroup_allsum_dpp<COLS>(sq) * invD * qsc_c, nmk = -rowgroup_allsum_dpp<COLS>(sk) * invD * ksc_c;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    xq[e] = live ? (xq[e] - mq) * qsc : 0.f;
-                    xk[e] = live ? (xk[e] - mk) * ksc : 0.f;
+                    xq[e] = fmaf(xq[e], qsc_c, nmq);
+                    xk[e] = fmaf(xk[e], ksc_c, nmk);
                 }
                 stage_floats<DP, EPL, 1>(smem, QI, row, scol, xq);
                 stage_floats<DP, EPL, 1>(smem, KI, row, scol, xk);
@@ -501,6 +507,10 @@ bool mfma_bf16_supported(const fastmax_problem& p) {
 
 int launch_fwd_mfma_bf16(const FwdArgs& a, const float* qscale, const float* kscale) {
     if (!mfma_bf16_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    // 31-bit buffer offsets inside one (b,h) slab; anything larger goes to the generic kernel (64-bit addresses)
+    if (!(quad32_span_ok(a.qs.sn, a.prob.Nq, a.prob.D, 2) && quad32_span_ok(a.ks.sn, a.prob.Nq, a.prob.D, 2) &&
+          quad32_span_ok(a.vs.sn, a.prob.Nq, a.prob.D, 2)))
+        return launch_fwd_mfma_gen(a, qscale, kscale);
     const SplitPlan plan = split_plan(a.prob);
     const int dp = a.prob.D <= 64 ? 64 : 128;
     if (plan.nseg > 1) {

@@ -265,6 +265,20 @@ template <int COLS> __device__ __forceinline__ float rowgroup_allsum(float v) {
 
 
 
+
+// sum over the COLS (8 or 16) consecutive lanes that hold one staged row, delivered to EVERY lane of the group, in DPP
+// instructions only (quad permutes for the xor-1 / xor-2 steps, row_half_mirror and row_mirror for the 4- and 8-lane steps):
+// 3 / 4 v_add_f32 instead of a ds_bpermute + add per step
+template <int COLS> __device__ __forceinline__ float rowgroup_allsum_dpp(float v) {
+    static_assert(COLS == 8 || COLS == 16, "one or half a DPP row");
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    if constexpr (COLS == 16)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)); // row_mirror
+    return v;
+}
+
 // Same, but staged in the OUTPUT dtype through a wave-private area, so no workgroup barrier is needed: the 16 image
 // rows a wave alone reads (its query rows) are free once their fragments sit in registers.  area0 / area1 are the
 // two 16-row blocks (2*DP bytes per row) of a two-part image; a 4-byte result row is split across them, a 2-byte
@@ -346,5 +360,38 @@ struct TileLoader {
         }
     }
 };
+
+
+// 64-row tiles of one (b,h) slab of a (N, D) tensor through a buffer descriptor (staging map: row = srow + ps*RPP,
+// 16-byte piece scol).  The record count is the slab's own byte range, so rows past the tensor read as zero in
+// hardware (the range check covers the VGPR offset, which is why the tile offset is added there and not passed as the
+// scalar offset); lanes of a padded head column carry an offset that is always out of range.  A request costs NPASS
+// loads + NPASS integer adds, no compares.  The caller guarantees the slab spans less than 2 GiB (quad32_span_ok).
+// AUX: cache-policy bits of the loads (2 = non-temporal: tensors that are streamed exactly once)
+template <typename TIN, int NPASS, int RPP, int AUX = 0>
+struct BufTileLoader {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[NPASS];
+    int tile_bytes;
+    __device__ __forceinline__ BufTileLoader(const TIN* base, int64_t sn, int nrows, int D, int srow, int scol) {
+        constexpr int EPL = InTraits<TIN>::EPL;
+        const int row_bytes = (int)sn * (int)sizeof(TIN);
+        const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(base), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+            voff[ps] = scol * EPL < D ? (srow + ps * RPP) * row_bytes + scol * 16 : (int)0x80000000;
+        tile_bytes = 64 * row_bytes;
+    }
+    __device__ __forceinline__ void load(int tile, u32x4 (&r)[NPASS]) const {
+        const int t = tile * tile_bytes;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ps] + t, 0, AUX);
+    }
+};
+// host side: the byte range of one (b,h) slab fits the 31-bit offsets above
+inline bool quad32_span_ok(int64_t sn, int nrows, int D, int elem_bytes) {
+    return sn >= 0 && ((int64_t)(nrows > 0 ? nrows - 1 : 0) * sn + D) * elem_bytes < (int64_t)0x40000000;
+}
 
 }  // namespace fastmax

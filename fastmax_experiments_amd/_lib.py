@@ -31,7 +31,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s",
            "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed",
            "fastmax_hip_lmhead_ce_workspace", "fastmax_hip_lmhead_ce_forward", "fastmax_hip_lmhead_ce_backward",
-           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags"]
+           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags",
+           "fastmax_hip_normalize_stats2_workspace", "fastmax_hip_normalize_stats2"]
 
 
 class Problem(ctypes.Structure):
@@ -82,6 +83,10 @@ def lib():
     L.fastmax_hip_normalize.restype = ci
     L.fastmax_hip_normalize_stats.argtypes = [vp, i64p, ci, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize_stats.restype = ci
+    L.fastmax_hip_normalize_stats2_workspace.argtypes = [ci, ci, ci]
+    L.fastmax_hip_normalize_stats2_workspace.restype = sz
+    L.fastmax_hip_normalize_stats2.argtypes = [vp, i64p, vp, i64p, ci, fp, fp, ci, ci, ci, ci, vp, sz, vp]
+    L.fastmax_hip_normalize_stats2.restype = ci
     L.fastmax_hip_normalize_cast.argtypes = [vp, i64p, ci, vp, fp, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize_cast.restype = ci
     L.fastmax_hip_normalize_backward_workspace.argtypes = [ci, ci, ci]

@@ -246,6 +246,20 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
                                   reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t fastmax_hip_normalize_stats2_workspace(int B, int H, int N) {
+    return sizeof(unsigned int) * 2 * (size_t)B * H * (size_t)((N + 255) / 256);
+}
+
+int fastmax_hip_normalize_stats2(const void* x0, const int64_t* x0_strides, const void* x1, const int64_t* x1_strides, int dtype,
+                                 float* inv_norm0, float* inv_norm1, int B, int H, int N, int D, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!x0 || !x1 || !x0_strides || !x1_strides || !inv_norm0 || !inv_norm1) return FASTMAX_E_NULL;
+    if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D || (int64_t)B * H > 65535) return FASTMAX_E_BAD_SHAPE;
+    if (!workspace || workspace_bytes < fastmax_hip_normalize_stats2_workspace(B, H, N)) return FASTMAX_E_WORKSPACE;
+    return launch_normalize_stats2(x0, st(x0_strides), x1, st(x1_strides), dtype, inv_norm0, inv_norm1, B, H, N, D, workspace,
+                                   reinterpret_cast<hipStream_t>(stream));
+}
+
 int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtype, void* y, float* inv_norm, int B, int H,
                                int N, int D, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !x_strides || !y || !inv_norm) return FASTMAX_E_NULL;

@@ -635,6 +635,98 @@ int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_nor
     return FASTMAX_E_BAD_DTYPE;
 }
 
+// The linearmax forward needs the statistic of TWO tensors (q and k): one launch over both (blockIdx.z picks the tensor),
+// one word per 256-token block, and one small launch that folds the words into 1 / sqrt(max) -- 2 launches instead of 6
+// (zero words, maxima with atomics, finish; twice), which at (1,32,16384,128) was 27 us of launch gaps beside 73 us of reads.
+struct Max2Params {
+    const void* x[2];
+    Strides3 xs[2];
+    unsigned int* partials;      // [2][B*H][npart]
+    int H, N, D, vec[2];
+};
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void normalize_max2_kernel(Max2Params prm) {
+    constexpr int TOK = 256, EPL = 16 / sizeof(T), RPB = 256 / LPR;
+    __shared__ float wmax[4];
+    const int which = blockIdx.z;
+    const void* x = prm.x[which];
+    const Strides3 xs = prm.xs[which];
+    const int vec = prm.vec[which];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % LPR, rgrp = tid / LPR;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int N = prm.N, D = prm.D;
+    const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
+    float best = 0.f;
+    for (int n = n_begin + rgrp; n < n_end; n += RPB) {
+        const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
+        float v[EPL];
+        if (vec) {
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            u4 raw = {0, 0, 0, 0};
+            if (sub * EPL < D) raw = *reinterpret_cast<const u4*>(row + sub * EPL);      // the scan re-reads it: default policy
+            const T* pv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = (sub * EPL + e) < D ? to_float(pv[e]) : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = (sub * EPL + e) < D ? to_float(row[sub * EPL + e]) : 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += v[e];
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)D;
+        float nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float c = (sub * EPL + e) < D ? v[e] - mean : 0.f;
+            nn = fmaf(c, c, nn);
+        }
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) nn += __shfl_xor(nn, off, 64);
+        best = fmaxf(best, nn);
+    }
+    best = wave_max(best);
+    if (lane == 0) wmax[wave] = best;
+    __syncthreads();
+    if (tid == 0)
+        prm.partials[((int64_t)which * gridDim.y + bh) * gridDim.x + blockIdx.x] =
+            __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+}
+// inv[i] = 1 / sqrt(max over the npart words of row i); rows = 2 B H (q heads, then k heads)
+__global__ void normalize_finish_partials_kernel(const unsigned int* partials, int npart, float* inv0, float* inv1, int nheads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * nheads) return;
+    unsigned int m = 0u;
+    for (int j = 0; j < npart; ++j) m = max(m, partials[(int64_t)i * npart + j]);
+    (i < nheads ? inv0 : inv1)[i % nheads] = 1.0f / sqrtf(__uint_as_float(m));
+}
+template <typename T>
+static int launch_stats2_t(const void* x0, Strides3 s0, const void* x1, Strides3 s1, float* inv0, float* inv1, int B, int H, int N,
+                           int D, void* ws, hipStream_t stream) {
+    const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl, npart = (N + 255) / 256;
+    Max2Params prm{{x0, x1}, {s0, s1}, reinterpret_cast<unsigned int*>(ws), H, N, D, {rows_vec_ok(x0, s0, sizeof(T), D), rows_vec_ok(x1, s1, sizeof(T), D)}};
+    dim3 grid(npart, B * H, 2), block(256);
+    if (need <= 4) hipLaunchKernelGGL((normalize_max2_kernel<T, 4>), grid, block, 0, stream, prm);
+    else if (need <= 8) hipLaunchKernelGGL((normalize_max2_kernel<T, 8>), grid, block, 0, stream, prm);
+    else if (need <= 16) hipLaunchKernelGGL((normalize_max2_kernel<T, 16>), grid, block, 0, stream, prm);
+    else hipLaunchKernelGGL((normalize_max2_kernel<T, 32>), grid, block, 0, stream, prm);
+    hipLaunchKernelGGL(normalize_finish_partials_kernel, dim3((2 * B * H + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned int*>(ws), npart, inv0, inv1, B * H);
+    return (int)hipGetLastError();
+}
+int launch_normalize_stats2(const void* x0, Strides3 s0, const void* x1, Strides3 s1, int dtype, float* inv0, float* inv1, int B, int H,
+                            int N, int D, void* ws, hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: return launch_stats2_t<float>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
+        case FASTMAX_BF16: return launch_stats2_t<bf16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
+        case FASTMAX_F16: return launch_stats2_t<f16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
 int launch_normalize(const void* x, Strides3 xs, int dtype, float* y, float* inv_norm, int B, int H, int N, int D,
                      void* workspace, hipStream_t stream) {
     switch (dtype) {

@@ -24,14 +24,17 @@ struct StateParams {
 
 // RS = false: forward states of segments 0 .. nseg-2 (record seg).  RS = true: the reverse-scan states of the p=1 backward
 // (fastmax_mfma_bwd_lin.hip) of segments 1 .. nseg-1 (record seg-1): R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e.
+// block = 4 DP threads: one wave per 16-column slab of the state (DP / 16 waves; round 3: eight waves at D = 128 instead of four
+// with two slabs each -- the pass is latency-bound, one workgroup per CU)
 template <int DP, typename TIN, bool NORM, bool RS = false>
-__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StateParams prm) {
+__global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
+    constexpr int NT = 4 * DP;
     constexpr int C = 64, IMG = C * DP * 2;
     constexpr int KI = 0, VI = NP * IMG, PARTV = 2 * NP * IMG;
-    constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = C / RPP;
+    constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = C / RPP;
     constexpr int PARTK = PARTV + RPP * DP * 4;
-    constexpr int MT = DP / 16, NSL = DP / 64;
+    constexpr int MT = DP / 16, NSL = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
     const bool colok = scol * EPL < D;
     float ksc = 1.f;
     if constexpr (NORM) ksc = prm.kscale[bh];
+    const float ksc_c = colok ? ksc : 0.f;
     const float invD = 1.0f / (float)D;
     const int nchunks = (N + C - 1) / C;
     const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
                 float sk = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) sk += xk[e];
-                const float mk = rowgroup_allsum<COLS>(sk) * invD;
-                const bool live = colok && (n0 + row < N);
+                // one fma per element; rows past N were loaded as zeros (mean 0), padded columns have a zero scale
+                const float nmk = -rowgroup_allsum<COLS>(sk) * invD * ksc_c;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) xk[e] = live ? (xk[e] - mk) * ksc : 0.f;
+                for (int e = 0; e < EPL; ++e) xk[e] = fmaf(xk[e], ksc_c, nmk);
                 stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
             } else {
                 stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void p1_state_kernel(StatePa
 #pragma unroll
             for (int i = 0; i < 4; ++i) rec[(16 * mt + 4 * q4 + i) * DP + 16 * (w + 4 * sl) + r] = s2acc[sl][mt][i];
     __syncthreads();
-    for (int t = tid; t < 2 * DP; t += 256) {
+    for (int t = tid; t < 2 * DP; t += NT) {
         const int col = t % DP;
         const float* part = reinterpret_cast<const float*>(smem + (t < DP ? PARTV : PARTK));
         float s = 0.f;
@@ -180,7 +184,7 @@ size_t split_workspace_bytes(const fastmax_problem& p, int dp) {
 
 template <int DP, typename TIN, bool NORM, bool RS = false>
 static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
-    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 256 / (DP / EPL);
+    constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 4 * DP / (DP / EPL);
     constexpr int lds = 2 * NP * 64 * DP * 2 + 2 * RPP * DP * 4;
     auto kern = p1_state_kernel<DP, TIN, NORM, RS>;
     static bool attr_set = false;
@@ -189,7 +193,7 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(256), lds, stream, prm);
+    hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(4 * DP), lds, stream, prm);
     const int rec = DP * DP + 2 * DP;
     // one record per head (two segments) is its own prefix
     if (prm.nseg > 2)

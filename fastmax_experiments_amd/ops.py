@@ -189,6 +189,23 @@ def normalize_stats(x):
     return inv
 
 
+def normalize_stats_pair(q, k):
+    """normalize_stats of q and of k in two launches in all (per-block maxima of both tensors, one fold)"""
+    if q.shape != k.shape or q.dtype != k.dtype or q.device != k.device or q.shape[0] * q.shape[1] > 65535:
+        return normalize_stats(q), normalize_stats(k)
+    L = _lib.lib()
+    dev = q.device
+    B, H, N, D = q.shape
+    qi = torch.empty((B, H), dtype=torch.float32, device=dev)
+    ki = torch.empty((B, H), dtype=torch.float32, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_normalize_stats2_workspace(B, H, N), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_normalize_stats2(q.data_ptr(), _strides(q), k.data_ptr(), _strides(k), _DT[q.dtype], qi.data_ptr(),
+                                            ki.data_ptr(), B, H, N, D, wsp, wsb.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_normalize_stats2")
+    return qi, ki
+
+
 def linearmax_forward_fused(q, k, v):
     """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
     Returns None when the shape / dtype is not covered (the caller then uses the unfused route)."""
@@ -198,7 +215,7 @@ def linearmax_forward_fused(q, k, v):
     if q.dtype not in _DT or D > 128:
         return None
     prob = _problem(q, k, q.dtype, q.dtype, 1, True, 1.0, 0.0)
-    qi, ki = normalize_stats(q), normalize_stats(k)
+    qi, ki = normalize_stats_pair(q, k)
     o = torch.empty((B, H, N, D), dtype=q.dtype, device=dev)
     wsb, wsp = _ws(L.fastmax_hip_forward_workspace(ctypes.byref(prob)), dev)
     with torch.cuda.device(dev):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace); 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -138,6 +138,13 @@ int fastmax_hip_normalize(const void* x, const int64_t* x_strides, int dtype,
 int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dtype, float* inv_norm,
                                 int B, int H, int N, int D, void* workspace, size_t workspace_bytes,
                                 void* stream);
+/* The same statistic for the two tensors the linearmax forward normalises (q and k, same shape and dtype), in two launches
+ * in all: per-block maxima of both tensors, then one fold into inv_norm0 / inv_norm1 (B*H floats each).
+ * workspace: fastmax_hip_normalize_stats2_workspace(B, H, N) bytes.  Reference: fastmax_hack.py:38-43. */
+size_t fastmax_hip_normalize_stats2_workspace(int B, int H, int N);
+int fastmax_hip_normalize_stats2(const void* x0, const int64_t* x0_strides, const void* x1, const int64_t* x1_strides, int dtype,
+                                 float* inv_norm0, float* inv_norm1, int B, int H, int N, int D, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /*      training route: y = (x - mean_D x) / max-norm written in the INPUT dtype (contiguous (B,H,N,D)) -- the reference
  *      keeps 16-bit tensors 16-bit between the prologue and the attention (fastmax_hack.py:38-43) -- plus inv_norm (B,H).

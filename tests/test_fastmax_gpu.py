@@ -305,6 +305,24 @@ def test_linearmax_fused_prologue(shape, dt, tol):
     assert qq.grad is not None and qq.grad.dtype == dt and torch.isfinite(qq.grad).all()
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 3, 700, 64), (1, 5, 257, 128), (1, 2, 70, 80), (3, 1, 4, 16)])
+def test_paired_prologue_statistics_match_the_single_tensor_pass(shape, dt):
+    """fastmax_hip_normalize_stats2 (q and k in two launches in all) == two fastmax_hip_normalize_stats passes, bit for bit,
+    also on strided (transposed-storage) views; and against the definition max_n ||x_n - mean(x_n)|| (fastmax_hack.py:38-43)"""
+    from fastmax_experiments_amd import ops
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    q = torch.randn(shape, generator=g).to(dt).cuda()
+    k = (torch.randn(shape, generator=g) * 1.7).to(dt).cuda()
+    kt = k.transpose(1, 2).contiguous().transpose(1, 2)                   # same values, (B, N, H, D) storage
+    for kk in (k, kt):
+        qi, ki = ops.normalize_stats_pair(q, kk)
+        assert torch.equal(qi, ops.normalize_stats(q)) and torch.equal(ki, ops.normalize_stats(kk))
+    xc = k.float() - k.float().mean(-1, keepdim=True)
+    want = 1.0 / xc.norm(dim=-1).amax(-1)
+    assert torch.allclose(ki, want, rtol=2e-6)
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("shape", [(1, 2, 4096, 64), (1, 3, 1500, 64), (1, 1, 2048, 32), (1, 2, 2100, 128), (2, 8, 1024, 64)])
 def test_sequence_split_for_few_heads(shape, dt, tol):

@@ -32,7 +32,8 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed",
            "fastmax_hip_lmhead_ce_workspace", "fastmax_hip_lmhead_ce_forward", "fastmax_hip_lmhead_ce_backward",
            "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags",
-           "fastmax_hip_normalize_stats2_workspace", "fastmax_hip_normalize_stats2"]
+           "fastmax_hip_normalize_stats2_workspace", "fastmax_hip_normalize_stats2",
+           "fastmax_hip_lora_down_dropout", "fastmax_hip_lora_tn_dropout", "fastmax_hip_lora_up_dropout", "fastmax_hip_lora_dropout_mask"]
 
 
 class Problem(ctypes.Structure):
@@ -144,6 +145,15 @@ def lib():
     L.fastmax_hip_lora_tn.argtypes = [vp, i64, vp, i64, vp, ci, ci, ci, vp, ci, ci, ci, vp]
     L.fastmax_hip_lora_tn.restype = ci
     L.fastmax_hip_lora_up.argtypes = [vp, i64, vp, i64, vp, i64, ci, vp, ci, ci, ci, vp]
+    cf = ctypes.c_float
+    L.fastmax_hip_lora_down_dropout.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, ci, vp, cf, vp]
+    L.fastmax_hip_lora_down_dropout.restype = ci
+    L.fastmax_hip_lora_tn_dropout.argtypes = [vp, i64, vp, i64, vp, ci, ci, ci, vp, ci, ci, ci, vp, cf, vp]
+    L.fastmax_hip_lora_tn_dropout.restype = ci
+    L.fastmax_hip_lora_up_dropout.argtypes = [vp, i64, vp, i64, vp, i64, ci, vp, ci, ci, ci, vp, cf, vp]
+    L.fastmax_hip_lora_up_dropout.restype = ci
+    L.fastmax_hip_lora_dropout_mask.argtypes = [vp, ci, ci, vp, cf, vp]
+    L.fastmax_hip_lora_dropout_mask.restype = ci
     L.fastmax_hip_normalize_cast_expand.argtypes = [vp, i64p, ci, vp, vp, ci, ci, ci, ci, ci, vp, sz, vp]
     L.fastmax_hip_normalize_cast_expand.restype = ci
     L.fastmax_hip_normalize_backward_expand.argtypes = [vp, i64p, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, sz, vp]

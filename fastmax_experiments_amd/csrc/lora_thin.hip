@@ -35,6 +35,38 @@ typedef unsigned int tu32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
+// LoRA dropout (lit_gpt/lora.py:175, 422: `self.lora_dropout(x)` on the branch input, finetune/lora.py:42 lora_dropout = 0.05)
+// inside the rank-r kernels: the keep mask of x (M x K) is never stored.  It is a counter-based function of
+// (seed, row, column), so the forward pass (down: x A^T) and the backward pass (tn: dA = d_ea^T dropout(x); up: dx += mask o
+// (d_ea A)) regenerate the same bits.  Element (m, k): 16 bits of lowbias32(seed ^ (m * ldw + k / 2)) -- the low half for an
+// even k, the high half for an odd one -- kept iff >= thresh = round(65536 p); kept values are scaled by 65536 / (65536 -
+// thresh) on the product side (the accumulators, not the operands).  The seed is read from device memory, so that a
+// captured HIP graph draws a fresh mask on every replay.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DropParams {
+    const unsigned int* seed;     // device pointer (2 words), null = no dropout
+    unsigned int thresh;          // of 65536
+    unsigned int ldw;             // words (pairs of columns) per mask row
+    float scale;                  // 1 / keep probability
+};
+__device__ __forceinline__ unsigned int drop_hash(unsigned int seed, unsigned int row, unsigned int word, unsigned int ldw) {
+    unsigned int x = seed ^ (row * ldw + word);
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+// and-mask for the two bf16 values of word `word` of mask row `row`
+__device__ __forceinline__ unsigned int drop_word_mask(unsigned int seed, unsigned int row, unsigned int word, const DropParams& d) {
+    const unsigned int h = drop_hash(seed, row, word, d.ldw);
+    return ((h & 0xffffu) >= d.thresh ? 0x0000ffffu : 0u) | ((h >> 16) >= d.thresh ? 0xffff0000u : 0u);
+}
+// zero the dropped elements of a 16-byte piece that starts at even column col0 of row
+__device__ __forceinline__ tu32x4 drop_piece(tu32x4 v, unsigned int seed, int row, int col0, const DropParams& d) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] &= drop_word_mask(seed, (unsigned int)row, (unsigned int)(col0 >> 1) + i, d);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // down
 // ---------------------------------------------------------------------------------------------------------------------
 struct DownParams {
@@ -43,9 +75,10 @@ struct DownParams {
     __bf16* e; int64_t lde;
     __bf16* et; int64_t ldet;      // may be null
     int M, K;
+    DropParams drop;
 };
 
-template <int RPB>   // RP = 16 RPB
+template <int RPB, bool DROP = false>   // RP = 16 RPB; DROP: x passes through the dropout mask
 __global__ __launch_bounds__(256) void lora_down_kernel(const DownParams p) {
     __shared__ float red[4][RPB][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -58,9 +91,12 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const DownParams p) {
 #pragma unroll
     for (int cb = 0; cb < RPB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nstep = p.K >> 6;
-    struct Step { tu32x4 x0, x1; bf16x8 b0[RPB], b1[RPB]; };
+    unsigned int seed = 0;
+    if constexpr (DROP) seed = p.drop.seed[0];
+    struct Step { tu32x4 x0, x1; bf16x8 b0[RPB], b1[RPB]; int kb; };
     auto fetch = [&](int d, Step& t) {
         const int kb = d << 6;
+        t.kb = kb;
         t.x0 = tu32x4{0, 0, 0, 0};
         t.x1 = tu32x4{0, 0, 0, 0};
         if (live) {
@@ -74,10 +110,15 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const DownParams p) {
         }
     };
     auto consume = [&](const Step& t) {
+        tu32x4 x0 = t.x0, x1 = t.x1;
+        if constexpr (DROP) {                       // the mask is applied when the piece is consumed: the hashing overlaps the loads
+            x0 = drop_piece(x0, seed, m, t.kb + 8 * q, p.drop);
+            x1 = drop_piece(x1, seed, m, t.kb + 32 + 8 * q, p.drop);
+        }
 #pragma unroll
         for (int cb = 0; cb < RPB; ++cb) {
-            acc[cb] = mfma(__builtin_bit_cast(bf16x8, t.x0), t.b0[cb], acc[cb]);
-            acc[cb] = mfma(__builtin_bit_cast(bf16x8, t.x1), t.b1[cb], acc[cb]);
+            acc[cb] = mfma(__builtin_bit_cast(bf16x8, x0), t.b0[cb], acc[cb]);
+            acc[cb] = mfma(__builtin_bit_cast(bf16x8, x1), t.b1[cb], acc[cb]);
         }
     };
     // this wave's steps are wave, wave + 4, ...; the sweep starts at a column that depends on the workgroup so that the
@@ -112,7 +153,8 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const DownParams p) {
         const int row = m0 + 4 * (l >> 4) + i, col = l & 15;
 #pragma unroll
         for (int cb = 0; cb < RPB; ++cb) {
-            const float s = (red[0][cb][i][l] + red[1][cb][i][l]) + (red[2][cb][i][l] + red[3][cb][i][l]);
+            float s = (red[0][cb][i][l] + red[1][cb][i][l]) + (red[2][cb][i][l] + red[3][cb][i][l]);
+            if constexpr (DROP) s *= p.drop.scale;
             const __bf16 v = (__bf16)s;
             if (row < p.M) p.e[(int64_t)row * p.lde + cb * 16 + col] = v;
             if (p.et) p.et[(int64_t)(cb * 16 + col) * p.ldet + row] = row < p.M ? v : (__bf16)0.f;
@@ -128,9 +170,10 @@ struct TnParams {
     const __bf16* x; int64_t ldx;
     float* part;                                   // (S, RP, ncols)
     int M, ncols, rps;                             // rows per split, a whole number of stages
+    DropParams drop;                               // DROP: X is dropout(x), the mask regenerated per piece (the scale is applied by the caller's reduce pass)
 };
 
-template <int RPB, int KS>   // stages of 32 KS rows
+template <int RPB, int KS, bool DROP = false>   // stages of 32 KS rows
 __global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
     constexpr int SR = 32 * KS, SB = SR * 128;                  // X stage: SR rows x 64 columns
     constexpr int RSA = 2 * SR + 16, AB = 16 * RPB * RSA;       // E^T stage: 16 RPB rows x SR columns, padded rows
@@ -161,11 +204,15 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
             if (c < 16 * RPB && mm < mend && mm + 4 <= p.etcols) t.a[i] = *reinterpret_cast<const tu32x2*>(p.et + (int64_t)c * p.ldet + mm);
         }
     };
-    auto stage = [&](const Regs& t, int buf) {
+    unsigned int seed = 0;
+    if constexpr (DROP) seed = p.drop.seed[0];
+    auto stage = [&](const Regs& t, int buf, int st) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             const int piece = tid + 256 * i, row = piece >> 3, chunk = piece & 7;
-            *reinterpret_cast<tu32x4*>(smem + buf * SB + img_off<64>(row, chunk)) = t.x[i];
+            tu32x4 xv = t.x[i];
+            if constexpr (DROP) xv = drop_piece(xv, seed, mbeg + st * SR + row, n0 + 8 * chunk, p.drop);
+            *reinterpret_cast<tu32x4*>(smem + buf * SB + img_off<64>(row, chunk)) = xv;
         }
 #pragma unroll
         for (int i = 0; i < NP8; ++i) {
@@ -189,14 +236,14 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
                 acc[cb] = mfma(u.v, b, acc[cb]);
             }
         }
-        if (st + 1 < nst) stage(next, buf ^ 1);
+        if (st + 1 < nst) stage(next, buf ^ 1, st + 1);
         __syncthreads();
     };
     Regs ra, rb;
     if (nst > 0) {
         fetch(0, ra);
         if (nst > 1) fetch(1, rb);
-        stage(ra, 0);
+        stage(ra, 0, 0);
     }
     __syncthreads();
     for (int st = 0; st < nst; st += 2) {
@@ -213,7 +260,7 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const TnParams p) {
 
 // out[c][n] (or out[n][c] when transposed) = sum_s part[s][c][n] for c < R, summed in split order; float32 or bf16
 __global__ __launch_bounds__(256) void lora_tn_reduce_kernel(const float* part, void* out, int S, int RP, int R, int ncols, int out_bf16,
-                                                             int transpose) {
+                                                             int transpose, float scale) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)R * ncols) return;
     const int c = (int)(i / ncols), n = (int)(i % ncols);
@@ -229,6 +276,7 @@ __global__ __launch_bounds__(256) void lora_tn_reduce_kernel(const float* part, 
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; k < S; ++k) s += src[(int64_t)k * plane];
+    s *= scale;                                                                          // 1 / keep probability under dropout, else 1
     const int64_t o = transpose ? (int64_t)n * R + c : i;
     if (out_bf16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)s;
     else reinterpret_cast<float*>(out)[o] = s;
@@ -261,6 +309,7 @@ struct UpParams {
     const float* bias;             // may be null
     int bn_t;
     int M, N, nslab, groups;       // groups: waves per column slab
+    DropParams drop;               // DROP: y[m][n] += keep(m, n) / (1 - p) * (e bn^T)[m][n]   (dx of the dropped-out LoRA input)
 };
 
 template <int NPL> struct UpVec;
@@ -273,7 +322,7 @@ __device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(
 // Each wave keeps one slab of 64 NPL columns (its Bn rows stay in registers) and walks row blocks of RU rows with a stride
 // of `groups` blocks, two blocks in flight: the loads of block i+1 are issued before block i is finished.  The block's
 // RU x R coefficients are fetched with one dword per lane and broadcast with v_readlane.
-template <int R, int NPL, int RU>
+template <int R, int NPL, int RU, bool DROP = false>
 __global__ __launch_bounds__(256) void lora_up_kernel(const UpParams p) {
     typedef typename UpVec<NPL>::type vec_t;
     static_assert(RU * R / 2 <= 64, "one dword of E per lane");
@@ -314,6 +363,8 @@ __global__ __launch_bounds__(256) void lora_up_kernel(const UpParams p) {
         }
     }
     struct Blk { vec_t y[RU]; unsigned int e; };
+    unsigned int seed = 0;
+    if constexpr (DROP) seed = p.drop.seed[0];
     const int eu = lane / (R / 2), ec = lane % (R / 2);                      // this lane's dword of the block's coefficients
     auto fetch = [&](int bi, Blk& t) {
         const int m = bi * RU;
@@ -329,19 +380,31 @@ __global__ __launch_bounds__(256) void lora_up_kernel(const UpParams p) {
         const int m = bi * RU;
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            float o[NPL];
+            float o[NPL], d[NPL];
 #pragma unroll
             for (int j = 0; j < NPL; j += 2) {
                 const unsigned int wv = t.y[u][j >> 1];
                 o[j] = bf_lo(wv) + bias[j];
                 o[j + 1] = bf_hi(wv) + bias[j + 1];
+                d[j] = d[j + 1] = 0.f;
             }
 #pragma unroll
             for (int c = 0; c < R; c += 2) {
                 const unsigned int wv = __builtin_amdgcn_readlane(t.e, u * (R / 2) + (c >> 1));
                 const float e0 = bf_lo(wv), e1 = bf_hi(wv);
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) o[j] = fmaf(e1, b[j][c + 1], fmaf(e0, b[j][c], o[j]));
+                for (int j = 0; j < NPL; ++j) {
+                    if constexpr (DROP) d[j] = fmaf(e1, b[j][c + 1], fmaf(e0, b[j][c], d[j]));
+                    else o[j] = fmaf(e1, b[j][c + 1], fmaf(e0, b[j][c], o[j]));
+                }
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int j = 0; j < NPL; j += 2) {
+                    const unsigned int km = drop_word_mask(seed, (unsigned int)(m + u), (unsigned int)((n + j) >> 1), p.drop);
+                    o[j] += (km & 0xffffu) ? d[j] * p.drop.scale : 0.f;
+                    o[j + 1] += (km >> 16) ? d[j + 1] * p.drop.scale : 0.f;
+                }
             }
             vec_t ov;
 #pragma unroll
@@ -366,7 +429,7 @@ template <int R, int NPL, int RU> static int up_launch(UpParams p, hipStream_t s
     static int resident = 0;                          // waves of this kernel the device holds at once
     if (!resident) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lora_up_kernel<R, NPL, RU>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lora_up_kernel<R, NPL, RU, false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident = per_cu * cus * 4 * env_int("FASTMAX_LORA_UP_OVERSUB", 1);
@@ -378,7 +441,8 @@ template <int R, int NPL, int RU> static int up_launch(UpParams p, hipStream_t s
     if (groups > nblk) groups = nblk;
     p.groups = groups;
     const int64_t waves = (int64_t)p.nslab * groups;
-    hipLaunchKernelGGL((lora_up_kernel<R, NPL, RU>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+    if (p.drop.seed) hipLaunchKernelGGL((lora_up_kernel<R, NPL, RU, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((lora_up_kernel<R, NPL, RU, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -419,8 +483,20 @@ using namespace fastmax;
 
 extern "C" {
 
-int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
-                          int64_t ldet, int M, int K, int RP, void* stream) {
+static DropParams make_drop(const void* seed, float p_drop, int cols) {
+    DropParams d{nullptr, 0u, (unsigned int)(cols / 2), 1.0f};
+    if (seed && p_drop > 0.f) {
+        unsigned int t = (unsigned int)(p_drop * 65536.0f + 0.5f);
+        if (t > 65535u) t = 65535u;
+        d.seed = reinterpret_cast<const unsigned int*>(seed);
+        d.thresh = t;
+        d.scale = 65536.0f / (float)(65536u - t);
+    }
+    return d;
+}
+
+static int lora_down_impl(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et, int64_t ldet, int M,
+                          int K, int RP, const void* seed, float p_drop, void* stream) {
     if (!x || !bt || !e) return FASTMAX_E_NULL;
     if (M <= 0 || K <= 0 || K % 64 || (RP != 16 && RP != 32) || lde < RP || ldx < K || ldbt < K) return FASTMAX_E_BAD_SHAPE;
     if (!aligned16(x, ldx) || !aligned16(bt, ldbt)) return FASTMAX_E_BAD_SHAPE;
@@ -430,12 +506,26 @@ int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ld
         rows = (int)(ldet / 16 * 16);                   // the transposed copy is zero filled up to its leading dimension
     }
     DownParams p{reinterpret_cast<const __bf16*>(x), ldx, reinterpret_cast<const __bf16*>(bt), ldbt, reinterpret_cast<__bf16*>(e), lde,
-                 reinterpret_cast<__bf16*>(et), ldet, M, K};
+                 reinterpret_cast<__bf16*>(et), ldet, M, K, make_drop(seed, p_drop, K)};
     const dim3 grid((rows + 15) / 16);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (RP == 16) hipLaunchKernelGGL((lora_down_kernel<1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((lora_down_kernel<2>), grid, dim3(256), 0, s, p);
+    if (p.drop.seed) {
+        if (RP == 16) hipLaunchKernelGGL((lora_down_kernel<1, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((lora_down_kernel<2, true>), grid, dim3(256), 0, s, p);
+    } else {
+        if (RP == 16) hipLaunchKernelGGL((lora_down_kernel<1, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((lora_down_kernel<2, false>), grid, dim3(256), 0, s, p);
+    }
     return (int)hipGetLastError();
+}
+
+int fastmax_hip_lora_down(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
+                          int64_t ldet, int M, int K, int RP, void* stream) {
+    return lora_down_impl(x, ldx, bt, ldbt, e, lde, et, ldet, M, K, RP, nullptr, 0.f, stream);
+}
+int fastmax_hip_lora_down_dropout(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
+                                  int64_t ldet, int M, int K, int RP, const void* seed, float p_drop, void* stream) {
+    return lora_down_impl(x, ldx, bt, ldbt, e, lde, et, ldet, M, K, RP, seed, p_drop, stream);
 }
 
 int64_t fastmax_hip_lora_tn_workspace(int M, int ncols, int RP) {
@@ -445,8 +535,8 @@ int64_t fastmax_hip_lora_tn_workspace(int M, int ncols, int RP) {
     return (int64_t)S * RP * ncols * 4;
 }
 
-int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose, int R,
-                        void* workspace, int M, int ncols, int RP, void* stream) {
+static int lora_tn_impl(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose, int R,
+                        void* workspace, int M, int ncols, int RP, const void* seed, float p_drop, void* stream) {
     if (!et || !x || !out || !workspace) return FASTMAX_E_NULL;
     if (M <= 0 || ncols <= 0 || ncols % 64 || (RP != 16 && RP != 32) || ldx < ncols || R <= 0 || R > RP) return FASTMAX_E_BAD_SHAPE;
     if (out_dtype != FASTMAX_F32 && out_dtype != FASTMAX_BF16) return FASTMAX_E_BAD_DTYPE;
@@ -455,28 +545,43 @@ int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx
     int S, rps;
     tn_plan(M, ncols, S, rps);
     TnParams p{reinterpret_cast<const __bf16*>(et), ldet, etcols, reinterpret_cast<const __bf16*>(x), ldx, reinterpret_cast<float*>(workspace),
-               M, ncols, rps};
+               M, ncols, rps, make_drop(seed, p_drop, ncols)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(ncols / 64, S);
+#define TN_LAUNCH(RPB, KS)                                                                                      \
+    do {                                                                                                        \
+        if (p.drop.seed) hipLaunchKernelGGL((lora_tn_kernel<RPB, KS, true>), grid, dim3(256), 0, s, p);         \
+        else hipLaunchKernelGGL((lora_tn_kernel<RPB, KS, false>), grid, dim3(256), 0, s, p);                    \
+    } while (0)
     if (tn_ks() == 4) {
-        if (RP == 16) hipLaunchKernelGGL((lora_tn_kernel<1, 4>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((lora_tn_kernel<2, 4>), grid, dim3(256), 0, s, p);
+        if (RP == 16) TN_LAUNCH(1, 4);
+        else TN_LAUNCH(2, 4);
     } else {
-        if (RP == 16) hipLaunchKernelGGL((lora_tn_kernel<1, 2>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((lora_tn_kernel<2, 2>), grid, dim3(256), 0, s, p);
+        if (RP == 16) TN_LAUNCH(1, 2);
+        else TN_LAUNCH(2, 2);
     }
+#undef TN_LAUNCH
     const int64_t n = (int64_t)R * ncols;
     hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), out, S,
-                       RP, R, ncols, out_dtype == FASTMAX_BF16, transpose);
+                       RP, R, ncols, out_dtype == FASTMAX_BF16, transpose, p.drop.scale);
     return (int)hipGetLastError();
 }
+int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose, int R,
+                        void* workspace, int M, int ncols, int RP, void* stream) {
+    return lora_tn_impl(et, ldet, x, ldx, out, out_dtype, transpose, R, workspace, M, ncols, RP, nullptr, 0.f, stream);
+}
+int fastmax_hip_lora_tn_dropout(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose, int R,
+                                void* workspace, int M, int ncols, int RP, const void* seed, float p_drop, void* stream) {
+    return lora_tn_impl(et, ldet, x, ldx, out, out_dtype, transpose, R, workspace, M, ncols, RP, seed, p_drop, stream);
+}
 
-int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
-                        const float* bias, int M, int N, int R, void* stream) {
+static int lora_up_impl(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                        const float* bias, int M, int N, int R, const void* seed, float p_drop, void* stream) {
     if (!y || !e || !bn) return FASTMAX_E_NULL;
     if (M <= 0 || N <= 0 || N % 8 || ldy < N || lde < R || ldb < (bn_transposed ? N : R)) return FASTMAX_E_BAD_SHAPE;
     if (!aligned16(y, ldy) || !aligned16(e, lde) || !aligned16(bn, ldb)) return FASTMAX_E_BAD_SHAPE;
-    UpParams p{reinterpret_cast<__bf16*>(y), ldy, reinterpret_cast<const __bf16*>(e), lde, reinterpret_cast<const __bf16*>(bn), ldb, bias, bn_transposed ? 1 : 0, M, N, 0, 0};
+    UpParams p{reinterpret_cast<__bf16*>(y), ldy, reinterpret_cast<const __bf16*>(e), lde, reinterpret_cast<const __bf16*>(bn), ldb, bias, bn_transposed ? 1 : 0, M, N, 0, 0,
+               make_drop(seed, p_drop, N)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const int variant = env_int("FASTMAX_LORA_UP_VARIANT", 0);
     switch (R) {
@@ -492,6 +597,33 @@ int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const 
         case 32: return up_launch<32, 4, 4>(p, s);
     }
     return FASTMAX_E_BAD_SHAPE;
+}
+int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                        const float* bias, int M, int N, int R, void* stream) {
+    return lora_up_impl(y, ldy, e, lde, bn, ldb, bn_transposed, bias, M, N, R, nullptr, 0.f, stream);
+}
+int fastmax_hip_lora_up_dropout(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                                const float* bias, int M, int N, int R, const void* seed, float p_drop, void* stream) {
+    return lora_up_impl(y, ldy, e, lde, bn, ldb, bn_transposed, bias, M, N, R, seed, p_drop, stream);
+}
+
+// the keep mask itself (1 = kept), M x K bytes: what the three kernels above regenerate on the fly (tests, inspection)
+__global__ __launch_bounds__(256) void lora_dropout_mask_kernel(unsigned char* mask, int M, int K, fastmax::DropParams d) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ldw = K / 2;
+    if (w >= (int64_t)M * ldw) return;
+    const int row = (int)(w / ldw), word = (int)(w % ldw);
+    const unsigned int km = fastmax::drop_word_mask(d.seed[0], (unsigned int)row, (unsigned int)word, d);
+    mask[(int64_t)row * K + 2 * word] = (km & 0xffffu) ? 1 : 0;
+    mask[(int64_t)row * K + 2 * word + 1] = (km >> 16) ? 1 : 0;
+}
+int fastmax_hip_lora_dropout_mask(void* mask, int M, int K, const void* seed, float p_drop, void* stream) {
+    if (!mask || !seed) return FASTMAX_E_NULL;
+    if (M <= 0 || K <= 0 || K % 2 || !(p_drop > 0.f)) return FASTMAX_E_BAD_SHAPE;
+    const int64_t n = (int64_t)M * (K / 2);
+    hipLaunchKernelGGL(lora_dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<unsigned char*>(mask), M, K, make_drop(seed, p_drop, K));
+    return (int)hipGetLastError();
 }
 
 int fastmax_hip_lora_scatter(const void* b, int b_dtype, int r, const int32_t* rowmap, int n_parts, float scaling, void* et,

@@ -391,22 +391,50 @@ def _pad_rank(r: int) -> int:
     return 16 if r <= 16 else 32
 
 
-def lora_down(x: torch.Tensor, bt: torch.Tensor, want_t: bool = True):
-    """e (M, RP) = x (M, K) bt (RP, K)^T, and e^T (RP, roundup(M, 16)) zero padded; bf16."""
+def lora_down(x: torch.Tensor, bt: torch.Tensor, want_t: bool = True, drop=None):
+    """e (M, RP) = x (M, K) bt (RP, K)^T, and e^T (RP, roundup(M, 16)) zero padded; bf16.
+    drop = (seed tensor on the device, p): x passes through the dropout mask of that seed first (scaled by 1 / (1 - p))."""
     M, K = x.shape
     RP = bt.shape[0]
     e = torch.empty((M, RP), dtype=torch.bfloat16, device=x.device)
     MP = (M + 15) // 16 * 16
     et = torch.empty((RP, MP), dtype=torch.bfloat16, device=x.device) if want_t else None
     with torch.cuda.device(x.device):
-        rc = _lib.lib().fastmax_hip_lora_down(x.data_ptr(), x.stride(0), bt.data_ptr(), bt.stride(0), e.data_ptr(), RP,
-                                              None if et is None else et.data_ptr(), MP, M, K, RP, _stream(x.device))
+        if drop is None:
+            rc = _lib.lib().fastmax_hip_lora_down(x.data_ptr(), x.stride(0), bt.data_ptr(), bt.stride(0), e.data_ptr(), RP,
+                                                  None if et is None else et.data_ptr(), MP, M, K, RP, _stream(x.device))
+        else:
+            rc = _lib.lib().fastmax_hip_lora_down_dropout(x.data_ptr(), x.stride(0), bt.data_ptr(), bt.stride(0), e.data_ptr(), RP,
+                                                          None if et is None else et.data_ptr(), MP, M, K, RP, drop[0].data_ptr(),
+                                                          float(drop[1]), _stream(x.device))
     _lib.check(rc, "fastmax_hip_lora_down")
     return e, et
 
 
-def lora_tn(et: torch.Tensor, x: torch.Tensor, R: int = None, dtype=torch.float32, transpose: bool = False) -> torch.Tensor:
-    """et[:R] (R, M) x (M, ncols) -> (R, ncols), or (ncols, R) when ``transpose``; float32 sums, result float32 or bf16."""
+def new_dropout_seed(device) -> torch.Tensor:
+    """one fresh 32-bit seed on the device, drawn from torch's device generator (so torch.manual_seed reproduces the masks and a
+    captured HIP graph draws a new one on every replay)"""
+    return torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=device)
+
+
+def dropout_mask(seed: torch.Tensor, M: int, K: int, p: float) -> torch.Tensor:
+    """the (M, K) keep mask the rank-r kernels regenerate from `seed` (bool tensor; tests / inspection)"""
+    mask = torch.empty((M, K), dtype=torch.uint8, device=seed.device)
+    with torch.cuda.device(seed.device):
+        rc = _lib.lib().fastmax_hip_lora_dropout_mask(mask.data_ptr(), M, K, seed.data_ptr(), float(p), _stream(seed.device))
+    _lib.check(rc, "fastmax_hip_lora_dropout_mask")
+    return mask.bool()
+
+
+def dropout_scale(p: float) -> float:
+    """1 / keep probability as the kernels apply it (the threshold is a 16-bit integer)"""
+    t = min(65535, int(p * 65536.0 + 0.5))
+    return 65536.0 / (65536 - t)
+
+
+def lora_tn(et: torch.Tensor, x: torch.Tensor, R: int = None, dtype=torch.float32, transpose: bool = False, drop=None) -> torch.Tensor:
+    """et[:R] (R, M) x (M, ncols) -> (R, ncols), or (ncols, R) when ``transpose``; float32 sums, result float32 or bf16.
+    drop = (seed, p): x is replaced by dropout(x) of that seed."""
     M, ncols = x.shape
     RP = et.shape[0]
     R = RP if R is None else R
@@ -418,20 +446,31 @@ def lora_tn(et: torch.Tensor, x: torch.Tensor, R: int = None, dtype=torch.float3
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     out = torch.empty((ncols, R) if transpose else (R, ncols), dtype=kdt, device=x.device)
     with torch.cuda.device(x.device):
-        rc = L.fastmax_hip_lora_tn(et.data_ptr(), et.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
-                                   _lib.BF16 if kdt == torch.bfloat16 else _lib.F32, int(transpose), R, ws.data_ptr(),
-                                   M, ncols, RP, _stream(x.device))
+        if drop is None:
+            rc = L.fastmax_hip_lora_tn(et.data_ptr(), et.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                                       _lib.BF16 if kdt == torch.bfloat16 else _lib.F32, int(transpose), R, ws.data_ptr(),
+                                       M, ncols, RP, _stream(x.device))
+        else:
+            rc = L.fastmax_hip_lora_tn_dropout(et.data_ptr(), et.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                                               _lib.BF16 if kdt == torch.bfloat16 else _lib.F32, int(transpose), R, ws.data_ptr(),
+                                               M, ncols, RP, drop[0].data_ptr(), float(drop[1]), _stream(x.device))
     _lib.check(rc, "fastmax_hip_lora_tn")
     return out if dtype == kdt else out.to(dtype)
 
 
-def lora_up_(y: torch.Tensor, e: torch.Tensor, bn: torch.Tensor, bias=None, transposed: bool = False) -> torch.Tensor:
-    """y (M, N) += e (M, R) bn^T (+ bias), in place; bn is (N, R), or (R, N) with ``transposed``; bf16, bias float32."""
+def lora_up_(y: torch.Tensor, e: torch.Tensor, bn: torch.Tensor, bias=None, transposed: bool = False, drop=None) -> torch.Tensor:
+    """y (M, N) += e (M, R) bn^T (+ bias), in place; bn is (N, R), or (R, N) with ``transposed``; bf16, bias float32.
+    drop = (seed, p): the added product passes through the dropout mask of that seed (y has the shape of the dropped-out x)."""
     M, N = y.shape
     with torch.cuda.device(y.device):
-        rc = _lib.lib().fastmax_hip_lora_up(y.data_ptr(), y.stride(0), e.data_ptr(), e.stride(0), bn.data_ptr(), bn.stride(0),
-                                            int(transposed), None if bias is None else bias.data_ptr(), M, N, e.shape[1],
-                                            _stream(y.device))
+        if drop is None:
+            rc = _lib.lib().fastmax_hip_lora_up(y.data_ptr(), y.stride(0), e.data_ptr(), e.stride(0), bn.data_ptr(), bn.stride(0),
+                                                int(transposed), None if bias is None else bias.data_ptr(), M, N, e.shape[1],
+                                                _stream(y.device))
+        else:
+            rc = _lib.lib().fastmax_hip_lora_up_dropout(y.data_ptr(), y.stride(0), e.data_ptr(), e.stride(0), bn.data_ptr(), bn.stride(0),
+                                                        int(transposed), None if bias is None else bias.data_ptr(), M, N, e.shape[1],
+                                                        drop[0].data_ptr(), float(drop[1]), _stream(y.device))
     _lib.check(rc, "fastmax_hip_lora_up")
     return y
 
@@ -559,7 +598,7 @@ class _QLoRAGemmFn(torch.autograd.Function):
     its last step, x A^T / dy eb by lora_down, dA / dB by lora_tn."""
 
     @staticmethod
-    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused, rope=None, owner=None):
+    def forward(ctx, x2, A, ebt, wq, scales, bias, N, K, wdense, fused, rope=None, owner=None, drop_p=0.0):
         """rope = (cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand): the product is an attention sub-layer's qkv
         projection and leaves the kernel as (q, k, v) -- de-interleaved and rotated, in the layout of ops.RopeQKVSplit's
         `expand` mode 0 (k, v at their G heads; also mode 1 when qpk == 1), 3 or 4 (stride-0 group views) -- instead of y"""
@@ -570,7 +609,10 @@ class _QLoRAGemmFn(torch.autograd.Function):
         else:
             abt = torch.zeros((RP, K), dtype=torch.bfloat16, device=x2.device)
             abt[:R] = A.detach()
-        ea, eat = lora_down(x2, abt)
+        # LoRA dropout (lit_gpt/lora.py:175, 422): the branch sees dropout(x); the mask is a function of a per-call seed and is
+        # regenerated by the backward kernels (lora_thin.hip), never stored
+        ctx.drop = (new_dropout_seed(x2.device), float(drop_p)) if drop_p > 0.0 else None
+        ea, eat = lora_down(x2, abt, drop=ctx.drop)
         eb = ebt.t().contiguous()                                  # (N, RP): the B-side operand of the GEMM's last step
         ctx.save_for_backward(x2, eat, abt, ebt, wq)
         ctx.dims = (N, K, R, A.dtype)
@@ -613,12 +655,16 @@ class _QLoRAGemmFn(torch.autograd.Function):
                 wt = _dense_weight_t(wq, ctx.scales, N, K)
             else:
                 wt = _frozen_transpose(ctx.dense_owner) if ctx.dense_owner is not None else ctx.dense_base.t().contiguous()
-            dx = hip_gemm(dy, wt, None, None, d_ea, abt.t().contiguous(), K)
+            if ctx.drop is None:
+                dx = hip_gemm(dy, wt, None, None, d_ea, abt.t().contiguous(), K)
+            else:
+                # the branch's share of dx passes through the same mask: the frozen product alone, then one masked rank update
+                dx = lora_up_(hip_gemm(dy, wt, None, None, None, None, K), d_ea, abt, transposed=True, drop=ctx.drop)
         if ctx.needs_input_grad[1]:
-            dA = lora_tn(d_eat, x2, R, a_dt)
+            dA = lora_tn(d_eat, x2, R, a_dt, drop=ctx.drop)
         if ctx.needs_input_grad[2]:
             d_ebt = lora_tn(eat, dy, dtype=torch.bfloat16)
-        return dx, dA, d_ebt, None, None, None, None, None, None, None, None, None
+        return dx, dA, d_ebt, None, None, None, None, None, None, None, None, None, None
 
 
 class _QLoRAThinFn(torch.autograd.Function):
@@ -670,8 +716,9 @@ def thin_route(x: torch.Tensor, base: "NF4Linear") -> bool:
     return M >= DENSE_M or base._dense_cache is not None
 
 
-def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None):
-    """x: (..., K) bf16 device tensor; A: (r, K); ebt: (RP, N) bf16 operand of the branch (scaling applied, rank zero padded)."""
+def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None, drop_p: float = 0.0):
+    """x: (..., K) bf16 device tensor; A: (r, K); ebt: (RP, N) bf16 operand of the branch (scaling applied, rank zero padded);
+    drop_p: LoRA dropout probability in effect (0 outside training)."""
     N, K = base.out_features, base.in_features
     if K % 128 or N % 64:
         raise NotImplementedError(f"fused NF4 linear needs in_features % 128 == 0 and out_features % 64 == 0, got {K}, {N}")
@@ -683,14 +730,16 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None):
         bias = bias.float()
     if not isinstance(base, NF4Linear):
         # a dense bf16 frozen base (LoRA without quantisation, lit_gpt/lora.py:170-177): the same tile GEMM on the weight itself
-        y = _QLoRAGemmFn.apply(x2, A, ebt, None, None, bias, N, K, base.weight.data, False, rope, base)
+        y = _QLoRAGemmFn.apply(x2, A, ebt, None, None, bias, N, K, base.weight.data, False, rope, base, drop_p)
         return y if rope is not None else y.reshape(*x.shape[:-1], N)
     scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
         if rope is not None:
-            return _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, False, rope)
-        y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused")
+            return _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, False, rope, None, drop_p)
+        y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused", None, None, drop_p)
     else:
+        if drop_p > 0.0:
+            raise NotImplementedError("LoRA dropout on the many-rows route needs FASTMAX_QLORA_ROUTE=gemm (the default) or fused")
         y = _QLoRAThinFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache)
     return y.reshape(*x.shape[:-1], N)
 
@@ -804,26 +853,33 @@ class LoRALinear(LoRALayer):
     def _lora_enabled(self) -> bool:
         return self.r > 0 and not self.merged
 
+    def _drop_p(self) -> float:
+        """LoRA dropout probability in effect for this call (lit_gpt/lora.py:79-83: nn.Dropout in training mode, else identity)"""
+        d = self.lora_dropout
+        return float(d.p) if isinstance(d, nn.Dropout) and self.training else 0.0
+
+    def _hand_written_dropout_ok(self) -> bool:
+        """dropout inside the rank-r kernels exists on the tile-GEMM route (FASTMAX_QLORA_ROUTE=gemm / fused)"""
+        return self._drop_p() == 0.0 or QLORA_ROUTE != "library"
+
     def rope_fusable(self, x: torch.Tensor) -> bool:
         """would forward(x, rope=...) take the one-kernel route (qkv projection + de-interleave + RoPE)?"""
         if not (self._lora_enabled() and self.lora_A.shape[0] <= RANK_PAD):
             return False
         if not isinstance(self.linear, NF4Linear):
             return self._dense_base_on_tile_gemm(x)
-        no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
-        return no_dropout and thin_route(x, self.linear) and QLORA_ROUTE == "gemm"
+        return thin_route(x, self.linear) and QLORA_ROUTE == "gemm"
 
     def forward(self, x: torch.Tensor, rope=None) -> torch.Tensor:
         if not self._lora_enabled():
             return self.linear(x)
         if isinstance(self.linear, NF4Linear) and self.lora_A.shape[0] <= RANK_PAD:
-            no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
-            if no_dropout and thin_route(x, self.linear):
-                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope)
+            if thin_route(x, self.linear) and self._hand_written_dropout_ok():
+                return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope, self._drop_p())
             ea = F.linear(self.lora_dropout(x), self.lora_A.to(x.dtype))
             return qlora_linear(x, self.linear, ea, self._dense_rows() * self.scaling)
         if self._dense_base_on_tile_gemm(x):
-            return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope)
+            return qlora_linear_thin(x, self.linear, self.lora_A, self._dense_rows_t(), rope, self._drop_p())
         pretrained = self.linear(x)
         lora = (self.lora_dropout(x) @ self.lora_A.transpose(0, 1).to(x.dtype)) @ self._dense_rows().transpose(0, 1).to(x.dtype)
         return pretrained + lora * self.scaling
@@ -834,13 +890,12 @@ class LoRALinear(LoRALayer):
         lin = self.linear
         if isinstance(lin, NF4Linear) or not isinstance(lin, nn.Linear) or os.environ.get("FASTMAX_DENSE_LORA_GEMM", "1") == "0":
             return False
-        no_dropout = not isinstance(self.lora_dropout, nn.Dropout) or not self.training or self.lora_dropout.p == 0
         M = x.numel() // x.shape[-1]
         w = lin.weight
         # the tile GEMM's autograd function treats the base (weight AND bias) as frozen data: a trainable bias
         # (mark_only_lora_as_trainable(bias="all" / "lora_only"), lit_gpt/lora.py:436-461) stays on the tensor-op route
         frozen_bias = lin.bias is None or not lin.bias.requires_grad
-        return (no_dropout and LORA_THIN and QLORA_ROUTE == "gemm" and x.device.type == "cuda" and x.dtype == torch.bfloat16
+        return (LORA_THIN and QLORA_ROUTE == "gemm" and x.device.type == "cuda" and x.dtype == torch.bfloat16
                 and w.dtype == torch.bfloat16 and not w.requires_grad and frozen_bias and w.is_contiguous() and M >= DENSE_M
                 and self.lora_A.shape[0] <= RANK_PAD and lin.in_features % 128 == 0 and lin.out_features % 64 == 0)
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace); 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -338,6 +338,22 @@ int fastmax_hip_lora_tn(const void* et, int64_t ldet, const void* x, int64_t ldx
  *              rows when bn_transposed.  R in {8,16,24,32}, N % 8 == 0.                                                */
 int fastmax_hip_lora_up(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
                         const float* bias, int M, int N, int R, void* stream);
+/*        LoRA dropout (lit_gpt/lora.py:175, 422 `self.lora_dropout(x)`; finetune/lora.py:42 lora_dropout = 0.05) inside the
+ *        same three kernels.  The keep mask of the branch input x (M, K) is a counter-based function of (seed[0], row,
+ *        column) -- 16 hash bits per element, kept iff >= round(65536 p_drop) -- regenerated wherever it is needed and never
+ *        stored; `seed` is a DEVICE pointer (one 32-bit word is read), so a captured HIP graph can draw a new mask per replay.
+ *          down_dropout: e = dropout(x) . bt^T            (forward: x A^T)
+ *          tn_dropout:   out = et . dropout(x)            (backward: dA = d_ea^T dropout(x); x in the X role)
+ *          up_dropout:   y += mask o (e . bn^T) / (1 - p) (backward: dx of the branch; y has the shape of x)
+ *        with dropout(x) = mask o x / (1 - p); seed == NULL or p_drop <= 0 gives the plain product.
+ *        dropout_mask writes the M x K mask as bytes (1 = kept), for tests and inspection.                              */
+int fastmax_hip_lora_down_dropout(const void* x, int64_t ldx, const void* bt, int64_t ldbt, void* e, int64_t lde, void* et,
+                                  int64_t ldet, int M, int K, int RP, const void* seed, float p_drop, void* stream);
+int fastmax_hip_lora_tn_dropout(const void* et, int64_t ldet, const void* x, int64_t ldx, void* out, int out_dtype, int transpose,
+                                int R, void* workspace, int M, int ncols, int RP, const void* seed, float p_drop, void* stream);
+int fastmax_hip_lora_up_dropout(void* y, int64_t ldy, const void* e, int64_t lde, const void* bn, int64_t ldb, int bn_transposed,
+                                const float* bias, int M, int N, int R, const void* seed, float p_drop, void* stream);
+int fastmax_hip_lora_dropout_mask(void* mask, int M, int K, const void* seed, float p_drop, void* stream);
 /*        scatter: the (RP, N) bf16 operand of the branch from lora_B (n_rows, r; b_dtype F32 / BF16):
  *              et[part r + j][n] = scaling b[rowmap[part][n]][j], 0 where rowmap is -1 and in rows >= n_parts r
  *              (LoRAQKVLinear's lora_ind / zero_pad, lit_gpt/lora.py:263-342; one part with the identity map = LoRALinear).

@@ -242,21 +242,91 @@ def test_many_rows_route_matches_the_tensor_op_route(kind, monkeypatch):
     assert _rel(res[0][0], _dense_reference(layer, x)) < 2e-2
 
 
-def test_many_rows_route_is_skipped_under_dropout(monkeypatch):
-    """the rank-r route computes x A^T itself, so a layer with active LoRA dropout keeps the tensor-op branch"""
+def test_many_rows_route_keeps_the_hand_written_kernels_under_dropout(monkeypatch):
+    """LoRA dropout is part of the rank-r kernels (round 3): a layer in training mode with lora_dropout > 0 -- the reference's
+    default is 0.05, finetune/lora.py:42 -- stays on the hand-written route and hands it its dropout probability"""
     from fastmax_experiments_amd import lora
     torch.manual_seed(4)
     layer = lora.LoRALinear(128, 128, r=8, lora_alpha=16, lora_dropout=0.5)
     layer.quantize_base().cuda().to(torch.bfloat16)
-    called = []
-    monkeypatch.setattr(lora, "qlora_linear_thin", lambda *a, **k: called.append(1))
+    seen = []
+    real = lora.qlora_linear_thin
+    monkeypatch.setattr(lora, "qlora_linear_thin", lambda *a, **k: (seen.append(a[5] if len(a) > 5 else k.get("drop_p", 0.0)), real(*a, **k))[1])
     x = torch.randn(2048, 128, device="cuda", dtype=torch.bfloat16)
     layer.train()
     y = layer(x)
-    assert not called and y.shape == (2048, 128)
+    assert seen == [0.5] and y.shape == (2048, 128)
     layer.eval()
     layer(x)
-    assert called
+    assert seen == [0.5, 0.0]
+
+
+def _keep_mask_reference(seed_words, M, K, p):
+    """the documented mask function (lora_thin.hip): 16 bits of lowbias32(seed ^ (m * K/2 + k/2)) per element, kept iff >= t"""
+    import numpy as np
+    t = min(65535, int(p * 65536.0 + 0.5))
+    ldw = K // 2
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * ldw + np.arange(ldw, dtype=np.uint64)[None, :]) & 0xFFFFFFFF
+    x = (idx ^ np.uint64(seed_words[0] & 0xFFFFFFFF)).astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x21f0aaad)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x735a2d97)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    keep = np.empty((M, K), dtype=bool)
+    keep[:, 0::2] = (x & np.uint64(0xFFFF)) >= t
+    keep[:, 1::2] = (x >> np.uint64(16)) >= t
+    return keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.05, 0.5])
+def test_lora_dropout_mask_is_consistent_forward_and_backward(p):
+    """The keep mask is regenerated by three kernels (down: x A^T; tn: dA; up: dx): with the SAME mask taken from
+    fastmax_hip_lora_dropout_mask, dense float32 math must reproduce y, dx, dA, dB of the hand-written route -- i.e. forward and
+    backward saw one mask -- and the mask has the documented bits and the keep rate 1 - p."""
+    import numpy as np
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(21)
+    M, K, N, r = 2304, 256, 384, 8
+    layer = lora.LoRALinear(K, N, r=r, lora_alpha=16, lora_dropout=p, bias=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda().to(torch.bfloat16)
+    lora.mark_only_lora_as_trainable(layer)
+    layer.train()
+    x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    seeds = []
+    real_seed = lora.new_dropout_seed
+    lora.new_dropout_seed = lambda dev: (seeds.append(real_seed(dev)), seeds[-1])[1]
+    try:
+        y = layer(x)
+    finally:
+        lora.new_dropout_seed = real_seed
+    assert len(seeds) == 1
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    mask = lora.dropout_mask(seeds[0], M, K, p)
+    assert np.array_equal(mask.cpu().numpy(), _keep_mask_reference(seeds[0].cpu().numpy().astype(np.int64), M, K, p))
+    rate = float(mask.float().mean())
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / (M * K)) ** 0.5 + 2e-5
+    # dense float32 reference with that mask
+    W = layer.linear.dequantize().float()
+    xf = x.detach().float().requires_grad_(True)
+    A = layer.lora_A.detach().float().requires_grad_(True)
+    B = layer.lora_B.detach().float().requires_grad_(True)
+    xd = xf * mask.float() * lora.dropout_scale(p)
+    yr = xf @ W.float().t() + layer.linear.bias.float() + (xd @ A.t()) @ B.t() * layer.scaling
+    yr.backward(gy.float())
+    tol = lambda a: 3e-2 * float(a.abs().max())
+    assert float((y.float() - yr).abs().max()) <= tol(yr)
+    assert float((x.grad.float() - xf.grad).abs().max()) <= tol(xf.grad)
+    assert float((layer.lora_A.grad.float() - A.grad).abs().max()) <= tol(A.grad)
+    assert float((layer.lora_B.grad.float() - B.grad).abs().max()) <= tol(B.grad)
+    # the branch's share of dx alone (the frozen product removed) must vanish exactly where the mask dropped x
+    lora_dx = x.grad.float() - (gy.float() @ W.float())
+    dropped = ~mask
+    assert float(lora_dx[dropped].abs().max()) <= 2e-2 * float((gy.float() @ W.float()).abs().max())
+    # a second call draws another mask
+    y2 = layer(x.detach())
+    assert not torch.equal(y2, y.detach())
 
 
 @pytest.mark.parametrize("kind", ["linear", "qkv_gqa_qv", "qkv_gqa_all", "qkv_k_only"])

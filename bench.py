@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--attn", default="fastmax", choices=["fastmax", "linearmax"])
     ap.add_argument("--micro-batch", type=int, default=2)
     ap.add_argument("--accum", type=int, default=2, help="dp_step: gradient accumulation iterations per optimizer step and rank")
+    ap.add_argument("--lora-dropout", type=float, default=0.05, help="dp_step: LoRA dropout (finetune/lora.py:42 default 0.05)")
     ap.add_argument("--toy", action="store_true", help="dp_step: CPU stand-in model (rehearsal of the multi-rank control flow)")
     ap.add_argument("--graph", action="store_true", help="dp_step: replay each micro-batch (forward + backward) as one captured HIP graph")
     ap.add_argument("--allow-variant", action="store_true",
@@ -130,7 +131,7 @@ def dp_step_main(args, dev, rank, world, multi, json_fd):
     seq = args.seq if args.seq != 4096 or args.config == "Llama-2-7b-hf" else 2048       # config 3 default: seq 2048
     res = finetune_step.run(args.config, args.layers, args.attn, seq, args.micro_batch, args.accum, args.steps, args.warmup,
                             dev, rank=rank, world=world, toy=args.toy, precondition_ms=0.0 if args.toy else args.precondition_ms,
-                            graph=args.graph)
+                            graph=args.graph, lora_dropout=args.lora_dropout)
     if rank == 0:
         line = {
             "metric": "data-parallel QLoRA fine-tune step, tokens/sec (whole job)", "workload": "dp_step",
@@ -140,7 +141,7 @@ def dp_step_main(args, dev, rank, world, multi, json_fd):
             "data": "synthetic",
             "config": {"workload": f"dp_step: {args.layers} x QLoRA attention sub-layer ({'toy' if args.toy else args.config}, "
                                    f"{args.attn}), seq {seq}, micro-batch {args.micro_batch} x accum {args.accum} per rank, "
-                                   "lm-head cross entropy, AdamW on the LoRA parameters",
+                                   f"LoRA r=8 alpha=16 dropout={args.lora_dropout}, lm-head cross entropy, AdamW on the LoRA parameters",
                        "global_batch": args.micro_batch * args.accum * world,
                        "parallelism": f"dp{world} (batch sharded; one all-reduce of the flat LoRA-gradient bucket per step)"},
             "allreduce": {"ms": round(res["allreduce_ms"], 4), "bucket_bytes": res["bucket_bytes"],

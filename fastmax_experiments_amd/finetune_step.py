@@ -26,12 +26,14 @@ from . import dp
 class AttentionStack(nn.Module):
     """n_layer x (x + CausalSelfAttention(x)) with QLoRA linears, then the lm-head loss of finetune/lora.py:216-219."""
 
-    def __init__(self, config: str, n_layer: int, attn_alg: str, vocab: int = 32000, r: int = 8, alpha: int = 16):
+    def __init__(self, config: str, n_layer: int, attn_alg: str, vocab: int = 32000, r: int = 8, alpha: int = 16,
+                 lora_dropout: float = 0.05):
+        """r, alpha, lora_dropout: the reference's fine-tune defaults (finetune/lora.py:40-42)"""
         super().__init__()
         from .attention_block import CONFIG_SHAPES, CausalSelfAttention
         shape = CONFIG_SHAPES[config]
         self.n_embd = shape["n_embd"]
-        self.blocks = nn.ModuleList(CausalSelfAttention(attn_alg=attn_alg, r=r, alpha=alpha, **shape) for _ in range(n_layer))
+        self.blocks = nn.ModuleList(CausalSelfAttention(attn_alg=attn_alg, r=r, alpha=alpha, dropout=lora_dropout, **shape) for _ in range(n_layer))
         for b in self.blocks:
             nn.init.normal_(b.attn.lora_B, std=0.02)              # a non-zero branch, so every LoRA gradient is exercised
         g = torch.Generator().manual_seed(1234)
@@ -73,7 +75,8 @@ class ToyLoRA(nn.Module):
 
 
 def run(config: str, n_layer: int, attn_alg: str, seq: int, micro_batch: int, accum: int, steps: int, warmup: int, device,
-        rank: int = 0, world: int = 1, toy: bool = False, precondition_ms: float = 0.0, graph: bool = False) -> dict:
+        rank: int = 0, world: int = 1, toy: bool = False, precondition_ms: float = 0.0, graph: bool = False,
+        lora_dropout: float = 0.05) -> dict:
     """`warmup` untimed + `steps` timed optimizer steps; -> timings (seconds / milliseconds, this rank)."""
     on_gpu = device.type == "cuda"
     multi = dist.is_available() and dist.is_initialized() and world > 1
@@ -85,7 +88,8 @@ def run(config: str, n_layer: int, attn_alg: str, seq: int, micro_batch: int, ac
         cos = sin = None
     else:
         from .attention_block import build_rope_cache
-        model = AttentionStack(config, n_layer, attn_alg).prepare(device)
+        model = AttentionStack(config, n_layer, attn_alg, lora_dropout=lora_dropout).prepare(device)
+        model.train()
         x = torch.randn(accum, micro_batch, seq, model.n_embd, device=device, generator=gen).to(torch.bfloat16)
         tgt = torch.randint(0, model.lm_head.shape[0], (accum, micro_batch, seq), device=device, generator=gen)
         cos, sin = (t.to(torch.bfloat16) for t in build_rope_cache(seq, model.rope_n_elem, device=device))

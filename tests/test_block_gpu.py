@@ -422,7 +422,7 @@ def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
     finals, losses = [], []
     for graph in (False, True):
         torch.manual_seed(0)
-        model = finetune_step.AttentionStack("pythia-14m", 2, "fastmax", vocab=512).prepare(dev)
+        model = finetune_step.AttentionStack("pythia-14m", 2, "fastmax", vocab=512, lora_dropout=0.0).prepare(dev)   # no dropout: bitwise
         cos, sin = (t.to(torch.bfloat16) for t in build_rope_cache(T, model.rope_n_elem, device=dev))
         params = dp.trainable_lora_parameters(model)
         opt = torch.optim.AdamW(params, lr=1e-3)
@@ -437,6 +437,35 @@ def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
         finals.append(torch.cat([p.detach().float().reshape(-1) for p in params]).clone())
     assert losses[0] == losses[1]
     assert torch.equal(finals[0], finals[1])
+
+
+def test_lora_dropout_draws_a_new_mask_on_every_replay_of_a_captured_step():
+    """the dropout seed of the hand-written route is a device tensor drawn from torch's device generator inside the step: a
+    captured micro-batch replayed twice on the SAME batch sees two different masks (and so two different losses), while the
+    kernels themselves stay deterministic"""
+    from fastmax_experiments_amd import dp, finetune_step
+    from fastmax_experiments_amd.attention_block import build_rope_cache
+    dev = torch.device("cuda")
+    T, mb = 2048, 1                                                   # 2048 rows: the tile-GEMM route with in-kernel dropout
+    torch.manual_seed(0)
+    model = finetune_step.AttentionStack("pythia-14m", 1, "fastmax", vocab=512, lora_dropout=0.5).prepare(dev)
+    model.train()
+    cos, sin = (t.to(torch.bfloat16) for t in build_rope_cache(T, model.rope_n_elem, device=dev))
+    params = dp.trainable_lora_parameters(model)
+    opt = torch.optim.SGD(params, lr=0.0)
+    st = dp.DataParallelStepper(model, opt, dp.TrainArgs(global_batch_size=4 * mb, micro_batch_size=mb), lambda m, b: m.loss(b[0], b[1], cos, sin))
+    g = torch.Generator(device=dev).manual_seed(6)
+    x = torch.randn(mb, T, 128, device=dev, generator=g).to(torch.bfloat16)
+    tgt = torch.randint(0, 512, (mb, T), device=dev, generator=g)
+    st.capture((x, tgt))
+    assert st.accum == 4
+    st.micro_step((x, tgt))                                           # accumulating: the bucket holds this replay's gradient
+    g1 = st.bucket.flat.clone()
+    st.micro_step((x, tgt))
+    g2 = st.bucket.flat - g1
+    assert float(g1.abs().sum()) > 0 and torch.isfinite(g2).all()
+    # same batch, same deterministic kernels: equal gradients would mean the replay reused the recorded mask
+    assert not torch.allclose(g2, g1, rtol=1e-3, atol=0.0)
 
 
 @pytest.mark.parametrize("config,T,alg,tables16", [("tiny-llama-1.1b", 2048, "fastmax", False), ("tiny-llama-1.1b", 2048, "linearmax", False),

@@ -30,8 +30,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_normalize_cast_expand", "fastmax_hip_normalize_backward_expand", "fastmax_hip_tune",
            "fastmax_hip_nf4_linear_forward_s", "fastmax_hip_nf4_linear_backward_input_s", "fastmax_hip_nf4_dequantize_s",
            "fastmax_hip_qlora_gemm", "fastmax_hip_nf4_dequantize_transposed",
-           "fastmax_hip_lmhead_ce_workspace", "fastmax_hip_lmhead_ce_forward", "fastmax_hip_lmhead_ce_backward",
-           "fastmax_hip_debug_gemm_stamps", "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags",
+           "fastmax_hip_qlora_gemm_rope", "fastmax_hip_tune_get", "fastmax_hip_build_flags",
            "fastmax_hip_normalize_stats2_workspace", "fastmax_hip_normalize_stats2",
            "fastmax_hip_lora_down_dropout", "fastmax_hip_lora_tn_dropout", "fastmax_hip_lora_up_dropout", "fastmax_hip_lora_dropout_mask"]
 
@@ -128,16 +127,8 @@ def lib():
     L.fastmax_hip_qlora_gemm.restype = ci
     L.fastmax_hip_nf4_dequantize_transposed.argtypes = [vp, vp, vp, ci, ci, vp]
     L.fastmax_hip_nf4_dequantize_transposed.restype = ci
-    L.fastmax_hip_lmhead_ce_workspace.argtypes = [ci, ci]
-    L.fastmax_hip_lmhead_ce_workspace.restype = i64
-    L.fastmax_hip_lmhead_ce_forward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, i64, vp]
     L.fastmax_hip_qlora_gemm_rope.argtypes = [vp, i64, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.fastmax_hip_qlora_gemm_rope.restype = ci
-    L.fastmax_hip_debug_gemm_stamps.argtypes = [vp]
-    L.fastmax_hip_debug_gemm_stamps.restype = None
-    L.fastmax_hip_lmhead_ce_forward.restype = ci
-    L.fastmax_hip_lmhead_ce_backward.argtypes = [vp, i64, vp, vp, vp, ctypes.c_float, vp, i64, ci, ci, ci, i64, vp]
-    L.fastmax_hip_lmhead_ce_backward.restype = ci
     L.fastmax_hip_lora_down.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, ci, vp]
     L.fastmax_hip_lora_down.restype = ci
     L.fastmax_hip_lora_tn_workspace.argtypes = [ci, ci, ci]

@@ -3,11 +3,9 @@
 * ``chunked_cross_entropy(logits, targets, chunk_size=128, ignore_index=-1)`` -- lit_gpt/utils.py:228-272 (accepts the list of
   lm-head chunks that ``GPT.forward(..., lm_head_chunk_size=128)`` returns, lora.py:547-550, or one tensor); the row-wise
   cross entropy runs in libfastmax_hip.so (fastmax_ce.hip): one read of the logits forward, one read + one write backward.
-* ``lm_head_cross_entropy(x, weight, targets)`` -- the head and the loss together.  bf16 (the fine-tune step): one hand-written
-  kernel multiplies a 256 x 256 block of logits into its accumulators and reduces it there (nf4_gemm.hip, EPI 1 / 2) -- the
-  forward pass writes per-row scalars only, the backward pass writes d(logits) once, as bf16, straight from the recomputed
-  tile.  Other dtypes: logits one row-chunk at a time (library GEMM -> HIP cross entropy).  Nothing of size
-  (tokens x vocabulary) is kept between forward and backward either way.
+* ``lm_head_cross_entropy(x, weight, targets)`` -- the head and the loss together: logits = x W^T (a plain library GEMM), the
+  HIP row kernel, and either the logits kept once for the backward pass (the row kernel turns them into d(logits) in place,
+  dx = d(logits) W is the second plain product) or alive one row chunk at a time in both directions.
 
 There is no CPU fallback: device tensors only.
 """
@@ -173,76 +171,13 @@ class _LMHeadLoss(torch.autograd.Function):
         return dx, None if dw is None else dw.to(weight.dtype), None, None, None, None
 
 
-def fused_head_supported(x2d: torch.Tensor, weight: torch.Tensor) -> bool:
-    """can the on-chip head + loss kernel (nf4_gemm.hip, EPI 1 / 2 / 3) take this pair?"""
-    return (x2d.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
-            and x2d.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and weight.is_contiguous() and x2d.stride(1) == 1
-            and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
-
-
-class _LMHeadLossOnChip(torch.autograd.Function):
-    """the same mean loss with each 256 x 256 block of logits reduced in the accumulators of the matrix kernel that produced
-    it.  keep = False: the forward pass writes per-row scalars only and the backward pass recomputes the block and writes
-    d(logits) straight from it; keep = True: the same forward kernel also stores the bf16 logits (written once, never re-read
-    in the forward pass) and the backward pass is the row kernel in place + two plain products."""
-
-    @staticmethod
-    def forward(ctx, x2d, weight, targets1d, ignore_index, chunk_rows, keep=False):
-        M, K = x2d.shape
-        V = weight.shape[0]
-        L = _lib.lib()
-        loss = torch.empty(M, dtype=torch.float32, device=x2d.device)
-        lse = torch.empty(M, dtype=torch.float32, device=x2d.device)
-        ws = torch.empty(L.fastmax_hip_lmhead_ce_workspace(M, V), dtype=torch.uint8, device=x2d.device)
-        logits = torch.empty(M, V, dtype=torch.bfloat16, device=x2d.device) if keep else None
-        with torch.cuda.device(x2d.device):
-            rc = L.fastmax_hip_lmhead_ce_forward(x2d.data_ptr(), x2d.stride(0), weight.data_ptr(), targets1d.data_ptr(),
-                                                 loss.data_ptr(), lse.data_ptr(), ws.data_ptr(),
-                                                 None if logits is None else logits.data_ptr(), V, M, V, K, ignore_index,
-                                                 _stream(x2d.device))
-        _lib.check(rc, "fastmax_hip_lmhead_ce_forward")
-        n = scored_rows(targets1d, V, ignore_index).sum().clamp(min=1)
-        ctx.ignore_index, ctx.chunk_rows, ctx.keep = ignore_index, chunk_rows, keep
-        if keep:
-            ctx.save_for_backward(x2d, weight, targets1d, lse, n, logits)
-        else:
-            ctx.save_for_backward(x2d, weight, targets1d, lse, n)
-        return (loss.sum() / n).to(x2d.dtype)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        if ctx.keep:
-            return _kept_backward(ctx, grad_out)
-        x2d, weight, targets1d, lse, n = ctx.saved_tensors
-        M, K = x2d.shape
-        V = weight.shape[0]
-        scale = float(grad_out.float() / n)                                 # one host sync per backward (scalar loss)
-        dx = torch.empty_like(x2d) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros_like(weight, dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        rows = min(ctx.chunk_rows, M)
-        dz = torch.empty(rows, V, dtype=torch.bfloat16, device=x2d.device)  # the one (rows x vocabulary) buffer of the step
-        L = _lib.lib()
-        for r0 in range(0, M, rows):
-            xs, nr = x2d[r0:r0 + rows], min(rows, M - r0)
-            with torch.cuda.device(x2d.device):
-                rc = L.fastmax_hip_lmhead_ce_backward(xs.data_ptr(), xs.stride(0), weight.data_ptr(), targets1d[r0:].data_ptr(),
-                                                      lse[r0:].data_ptr(), ctypes.c_float(scale), dz.data_ptr(), dz.stride(0), nr,
-                                                      V, K, ctx.ignore_index, _stream(x2d.device))
-            _lib.check(rc, "fastmax_hip_lmhead_ce_backward")
-            if dx is not None:
-                torch.matmul(dz[:nr], weight, out=dx[r0:r0 + nr])            # plain matrix product: library GEMM
-            if dw is not None:
-                dw.addmm_(dz[:nr].t().float(), xs.float())
-        return dx, None if dw is None else dw.to(weight.dtype), None, None, None, None
-
-
-# which head: "library" (library GEMM + row kernel) or "onchip" (the hand-written kernel where it applies); and how many bytes of
-# logits the forward pass may keep for the backward pass (0: never keep -- recompute; the MI355X has 288 GB).
-# Measured (tools/bench_head.py, 16384 x 2048 -> 32000, forward + backward): library kept 3.60 ms, on-chip kept 4.23,
-# library recompute 5.33, on-chip recompute 5.75 -- the hand-written 256 x 256 loop runs at ~0.8 of hipBLASLt's rate and the
-# traffic it saves does not buy that back, so it is the opt-in (it is the route that never holds a tokens x vocabulary buffer
-# in the forward pass); keeping the logits saves the second x W^T product whichever kernel made them.
-HEAD_ROUTE = os.environ.get("FASTMAX_HEAD_ROUTE", "library")
+# The head's two big products (logits = x W^T and dx = d(logits) W; the head is frozen in LoRA fine-tuning, so there is no dW) are
+# PLAIN matrix products and go to the vendor library by decision; what is hand-written on this path is the row-wise cross entropy
+# (online max / sum over 16-byte loads, in place d(logits)).  Rounds 1-2 also carried a hand-written head with the logits reduced
+# in the GEMM's accumulators (never written): 4-17 % slower than library GEMM + row kernel at (16384, 2048 -> 32000) because
+# the 256 x 256 loop runs at ~0.9 of hipBLASLt's rate (profiles/r02_head_loss.md); it was retired in round 3 instead of being
+# carried as a second route.  How many bytes of logits the forward pass may keep for the backward pass (0: never keep --
+# recompute; the MI355X has 288 GB):
 HEAD_KEEP_BYTES = int(os.environ.get("FASTMAX_HEAD_KEEP_BYTES", str(8 << 30)))
 
 
@@ -258,7 +193,7 @@ def lm_head_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: torch.
     if x2d.dtype not in _DT:
         x2d = x2d.float()
     x2d, weight, t1d = x2d.contiguous(), weight.to(x2d.dtype), targets.reshape(-1).to(torch.int64).contiguous()
-    fn = _LMHeadLossOnChip if HEAD_ROUTE == "onchip" and fused_head_supported(x2d, weight) else _LMHeadLoss
+    fn = _LMHeadLoss
     wants_grad = torch.is_grad_enabled() and (x2d.requires_grad or weight.requires_grad)
     keep = wants_grad and x2d.shape[0] * weight.shape[0] * x2d.element_size() <= HEAD_KEEP_BYTES
     return fn.apply(x2d, weight, t1d, ignore_index, chunk_rows, keep)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 8   /* 8: + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: the lmhead_ce_* and debug_gemm_stamps entry points are gone: the head's two products are plain library GEMMs by decision, see DESIGN.md, and the losing GEMM loop variants were removed; + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -296,29 +296,6 @@ int fastmax_hip_qlora_gemm_rope(const void* x, int64_t ldx, const void* w, const
  *      (x := dy, w := W^T, M x K output).  N % 64 == 0, K % 64 == 0.                                                       */
 int fastmax_hip_nf4_dequantize_transposed(const uint8_t* wq, const fastmax_nf4_scales* scales, void* out, int N, int K,
                                           void* stream);
-
-/* ---- lm-head + cross entropy with the logits kept on chip (csrc/nf4_gemm.hip, the GEMM above with a reducing epilogue).
- *      Replaces, for a bias-free bf16 head, the pair  logits = model(input_ids, lm_head_chunk_size=128)  (lit_gpt/lora.py:547-550)
- *      + chunked_cross_entropy(logits, targets)  (lit_gpt/utils.py:228-272; called at finetune/lora.py:216-219): a 256 x 256 block
- *      of logits z = bf16(x W^T) lives in the accumulators of one workgroup and is reduced there.
- *      x [M][K] bf16 (leading dimension ldx), w [V][K] bf16, targets [M] int64; K % 64 == 0, V % 8 == 0, 16-byte aligned.
- *      forward : loss[m] = logsumexp_v z_mv - z_m,t(m)  (0 for rows that are not scored: t == ignore_index or outside [0, V)),
- *                lse[m] for the backward pass; workspace = fastmax_hip_lmhead_ce_workspace(M, V) bytes of scratch;
- *                logits non-null: the bf16 logits [M][V] (leading dimension ldz) are stored too, written once by the same
- *                kernel, and the backward pass is fastmax_hip_cross_entropy_backward in place over them (no second product).
- *      backward: dz[m][v] = (exp(z_mv - lse[m]) - [v == t(m)]) * grad_scale as bf16 (leading dimension ldz), rows that are
- *                not scored 0; dx = dz . W is a plain matrix product of the result.                                         */
-int64_t fastmax_hip_lmhead_ce_workspace(int M, int V);
-int fastmax_hip_lmhead_ce_forward(const void* x, int64_t ldx, const void* w, const int64_t* targets, float* loss, float* lse,
-                                  void* workspace, void* logits, int64_t ldz, int M, int V, int K, int64_t ignore_index,
-                                  void* stream);
-int fastmax_hip_lmhead_ce_backward(const void* x, int64_t ldx, const void* w, const int64_t* targets, const float* lse,
-                                   float grad_scale, void* dz, int64_t ldz, int M, int V, int K, int64_t ignore_index,
-                                   void* stream);
-
-/*      diagnostics: a device buffer of 4 x (workgroups) 64-bit words that later fastmax_hip_qlora_gemm launches fill with the
- *      main loop's (shader cycles, 100 MHz ticks, cycles waiting for its copies, cycles waiting at the barrier) per workgroup; null turns it off (tools/gemm_clock.py)                   */
-void fastmax_hip_debug_gemm_stamps(void* buffer);
 
 /* ---- QLoRA linear at training sizes: the rank-r products around the library GEMM of the frozen weight
  *      (csrc/lora_thin.hip).  Replaces the tensor ops of lit_gpt/lora.py:170-177 / :419-433 and their autograd mirror

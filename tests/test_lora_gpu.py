@@ -471,14 +471,11 @@ def test_training_size_qlora_layer_routes_agree(route, monkeypatch):
     assert _rel(x.grad, xa.grad) < 3e-2 and _rel(layer.lora_A.grad, A.grad) < 3e-2 and _rel(layer.lora_B.grad, B.grad) < 3e-2
 
 
-@pytest.mark.parametrize("sched", [8, 9, 10, 11, 14, 15, 17, 18, 20, 21])
-def test_gemm_loop_variants_match_the_default_kernel(sched):
-    """the other loop orders of the 256 x 256 GEMM (8 .. 11: fragments read under the MFMAs, copies issued by one wave of a SIMD
-    pair, both, staggered copies) and its four-wave forms ("gemm_sched" 20: 16x16x32 MFMAs in place by inline asm, operands
-    staged through registers; 21: 32x32x16 MFMAs on padded images): same sums in the same order per element as the default
-    8-wave kernel -> the same bits, bias and LoRA step included"""
+def test_plain_gemm_loop_matches_the_default_kernel():
+    """the A/B baseline kept from round 2 ("gemm_sched" 14: every wave issues its copies, reads its fragments, multiplies): same
+    sums in the same order per element as the default 8-wave kernel -> the same bits, bias and LoRA step included"""
     from fastmax_experiments_amd import _lib, lora
-    g = torch.Generator().manual_seed(sched)
+    g = torch.Generator().manual_seed(14)
     M, N, K = 1024, 768, 320
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
@@ -489,17 +486,14 @@ def test_gemm_loop_variants_match_the_default_kernel(sched):
     _lib.check(L.fastmax_hip_tune(b"gemm_sched", 13), "tune")        # the default 8-wave 256 x 256 kernel (128-row tiles forbidden)
     try:
         want = lora.hip_gemm(x, w, None, bias, ea, eb, N)
-        _lib.check(L.fastmax_hip_tune(b"gemm_sched", sched), "tune")
+        _lib.check(L.fastmax_hip_tune(b"gemm_sched", 14), "tune")
         got = lora.hip_gemm(x, w, None, bias, ea, eb, N)
         got_plain = lora.hip_gemm(x, w, None, None, None, None, N)
     finally:
         _lib.check(L.fastmax_hip_tune(b"gemm_sched", 0), "tune")
     ref = x.float() @ w.float().T
     assert _rel(got_plain, ref) < 1e-2
-    if sched != 21:
-        assert torch.equal(got, want)
-    else:                                                             # 16-deep instead of 32-deep products: another summation order
-        assert _rel(got, want) < 4e-3
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("kind", ["linear", "qkv"])

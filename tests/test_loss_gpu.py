@@ -110,90 +110,6 @@ def test_labels_outside_the_vocabulary():
     assert abs(float(l2) - float(ref2)) < 2e-3
 
 
-@pytest.mark.parametrize("keep", [False, True])
-@pytest.mark.parametrize("M,K,V,chunk", [(700, 256, 1000, 4096), (1300, 128, 4104, 512), (256, 64, 256, 100)])
-def test_on_chip_head_loss_against_the_row_kernel_route(M, K, V, chunk, keep):
-    """bf16 head + loss with the logits kept in the matrix kernel's accumulators (nf4_gemm.hip EPI 1 / 2) against the route that
-    writes bf16 logits with the library GEMM and reads them back in the row kernel: same rounding of the logits (bf16), so the
-    per-row losses agree to fp32 summation order; ragged row and column tails, ignored and out-of-vocabulary labels."""
-    from fastmax_experiments_amd.loss import _LMHeadLoss, _LMHeadLossOnChip, fused_head_supported
-    g = torch.Generator().manual_seed(M + V)
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
-    w = (torch.randn(V, K, generator=g) * 0.08).to(torch.bfloat16).cuda()
-    t = torch.randint(0, V, (M,), generator=g).cuda()
-    t[:9] = -1
-    t[11] = V + 3
-    t[12] = -100
-    t[13] = V - 1                                                    # last column of the ragged block
-    t[14] = 0
-    assert fused_head_supported(x, w)
-    res = []
-    for fn in (_LMHeadLossOnChip, _LMHeadLoss):
-        xa = x.clone().requires_grad_(True)
-        wa = w.clone().requires_grad_(True)
-        loss = fn.apply(xa, wa, t, -1, chunk, keep and fn is _LMHeadLossOnChip)   # the other side always recomputes
-        loss.backward()
-        res.append((loss.float(), xa.grad.float(), wa.grad.float()))
-    (l1, dx1, dw1), (l2, dx2, dw2) = res
-    assert abs(float(l1) - float(l2)) <= 4e-3 * abs(float(l2))     # the two results are bf16 scalars (3 significant digits)
-    assert float((dx1 - dx2).abs().max()) <= 2e-2 * float(dx2.abs().max())
-    assert float((dw1 - dw2).abs().max()) <= 2e-2 * float(dw2.abs().max())
-    assert float(dx1[:9].abs().sum()) == 0.0 and float(dx1[11:13].abs().sum()) == 0.0
-    # and against float64 on the same bf16-rounded logits
-    z = (x.double() @ w.double().t()).to(torch.bfloat16).double()
-    keep = (t >= 0) & (t < V)
-    ref = F.cross_entropy(z[keep], t[keep], reduction="mean")
-    assert abs(float(l1) - float(ref)) <= 6e-3 * abs(float(ref))
-
-
-def test_on_chip_head_loss_rows_exact():
-    """the C entry point's per-row losses and log-sum-exps against float64 on logits rounded to bf16 the same way"""
-    import ctypes
-    from fastmax_experiments_amd import _lib
-    from fastmax_experiments_amd.ops import _stream
-    g = torch.Generator().manual_seed(5)
-    M, K, V = 515, 192, 2056
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
-    w = (torch.randn(V, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
-    t = torch.randint(0, V, (M,), generator=g).cuda()
-    t[3] = -1
-    L = _lib.lib()
-    loss = torch.empty(M, device="cuda")
-    lse = torch.empty(M, device="cuda")
-    ws = torch.empty(L.fastmax_hip_lmhead_ce_workspace(M, V), dtype=torch.uint8, device="cuda")
-    kept = torch.empty(M, V, dtype=torch.bfloat16, device="cuda")
-    rc = L.fastmax_hip_lmhead_ce_forward(x.data_ptr(), K, w.data_ptr(), t.data_ptr(), loss.data_ptr(), lse.data_ptr(), ws.data_ptr(),
-                                         kept.data_ptr(), V, M, V, K, -1, _stream(x.device))
-    assert rc == 0
-    loss2, lse2 = torch.empty_like(loss), torch.empty_like(lse)
-    rc = L.fastmax_hip_lmhead_ce_forward(x.data_ptr(), K, w.data_ptr(), t.data_ptr(), loss2.data_ptr(), lse2.data_ptr(), ws.data_ptr(),
-                                         None, 0, M, V, K, -1, _stream(x.device))
-    assert rc == 0 and torch.equal(loss, loss2) and torch.equal(lse, lse2)      # storing the tile changes nothing else
-    z = (x.float() @ w.float().t()).to(torch.bfloat16).double()     # fp32 accumulation, one rounding: what the tile holds
-    ref_lse = torch.logsumexp(z, dim=1)
-    ref_loss = ref_lse - z.gather(1, t.clamp(min=0)[:, None])[:, 0]
-    ref_loss[3] = 0
-    # accumulation order differs from the library's: a logit can round to the neighbouring bf16 (2^-8 relative)
-    assert float((kept.double() - z).abs().max()) <= 2.0 ** -7 * float(z.abs().max())     # at most one bf16 step apart
-    assert float((torch.logsumexp(kept.double(), dim=1) - lse.double()).abs().max()) < 1e-4   # lse IS that of the stored logits
-    assert float((lse.double() - ref_lse).abs().max()) < 2e-2
-    assert float((loss.double() - ref_loss).abs().max()) < 6e-2
-    assert float(loss[3]) == 0.0
-    dz = torch.empty(M, V, dtype=torch.bfloat16, device="cuda")
-    rc = L.fastmax_hip_lmhead_ce_backward(x.data_ptr(), K, w.data_ptr(), t.data_ptr(), lse.data_ptr(), ctypes.c_float(0.5),
-                                          dz.data_ptr(), V, M, V, K, -1, _stream(x.device))
-    assert rc == 0
-    ref_dz = torch.softmax(z, dim=1)
-    ref_dz[torch.arange(M), t.clamp(min=0)] -= 1
-    ref_dz *= 0.5
-    ref_dz[3] = 0
-    assert float((dz.double() - ref_dz).abs().max()) < 1e-2
-    assert float(dz[3].abs().sum()) == 0.0
-    # argument checks: a contraction length that is not a whole number of 64-column steps
-    assert L.fastmax_hip_lmhead_ce_forward(x.data_ptr(), K, w.data_ptr(), t.data_ptr(), loss.data_ptr(), lse.data_ptr(),
-                                           ws.data_ptr(), None, 0, M, V, 100, -1, None) != 0
-
-
 def test_kept_logits_are_consumed_once():
     """the default fine-tune route keeps the bf16 logits and turns them into d(logits) in place: same loss and gradient as
     the recompute route, and a second backward pass through the same graph is refused instead of using the overwritten buffer"""

@@ -69,16 +69,12 @@ def main():
         row("library: x @ Wd^T (weight already dense)", lambda: x @ wd.t())
         row("library route: decode once + x @ Wd^T + addmm(ea, eb) + bias",
             lambda: (x @ lora._dense_weight(q.weight.data, scales, N, K).t()).addmm_(ea, eb.t()).add_(q.bias.to(torch.bfloat16)))
-        for sched, label in ((0, "default loop (copies by one wave of a SIMD pair, fragments read under the MFMAs)"), (14, "first loop of round 2 (every wave: copies, reads, MFMAs)"), (6, "LDS-DMA pieces between the MFMA groups"),
-                             (7, "staging through registers (load, MFMAs, ds_write)"),
-                             (8, "fragments of the next half read under the MFMAs of this one"),
-                             (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced"),
-                             (20, "4 waves x 128 x 128, operands through registers, asm MFMAs"),
-                             (21, "4 waves, 32x32x16 MFMAs, padded images")):
+        for sched, label in ((0, "default loop (copies by one wave of a SIMD pair, fragments read under the MFMAs)"),
+                             (14, "plain loop (every wave: copies, reads, MFMAs)"), (12, "128 x 256 tiles"), (13, "256 x 256 tiles forced")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, dense bf16 W, {label} (+ bias + LoRA step)", lambda: gemm(x, wd, None, q.bias, ea, eb),
                 lambda: gemm(x, wd, None, q.bias, ea, eb))
-        for sched, label in ((14, "plain loop, decode after the MFMAs"), (0, "default"), (6, "decode words between the MFMA groups"), (7, "x through registers"), (8, "fragments read under the MFMAs")):
+        for sched, label in ((14, "plain loop, decode after the MFMAs"), (0, "default: fragments read under the MFMAs")):
             _lib.check(_lib.lib().fastmax_hip_tune(b"gemm_sched", sched), "tune")
             row(f"hand-written, NF4 decoded in the loop, {label} (+ bias + LoRA step)",
                 lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb), lambda: gemm(x, q.weight.data, scales, q.bias, ea, eb))

@@ -1,12 +1,12 @@
-"""lm-head + cross entropy at fine-tune sizes: the on-chip route (nf4_gemm.hip EPI 1 / 2) against the library-GEMM + row-kernel
-route, forward and forward+backward.  `python tools/bench_head.py [M K V]`"""
+"""lm-head + cross entropy at fine-tune sizes (library GEMM + HIP row kernel; logits kept for the backward pass or recomputed),
+forward and forward+backward.  `python tools/bench_head.py [M K V]`"""
 import sys
 import time
 
 import torch
 
 sys.path.insert(0, ".")
-from fastmax_experiments_amd.loss import _LMHeadLoss, _LMHeadLossOnChip  # noqa: E402
+from fastmax_experiments_amd.loss import _LMHeadLoss  # noqa: E402
 
 
 def timeit(f, n=10):
@@ -27,8 +27,7 @@ def main():
         x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         w = (torch.randn(V, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
         t = torch.randint(0, V, (M,), device="cuda", generator=g)
-        for name, fn, keep in (("on-chip, recompute", _LMHeadLossOnChip, False), ("on-chip, logits kept", _LMHeadLossOnChip, True),
-                               ("library + rows, recompute", _LMHeadLoss, False), ("library + rows, logits kept", _LMHeadLoss, True)):
+        for name, fn, keep in (("library + rows, recompute", _LMHeadLoss, False), ("library + rows, logits kept", _LMHeadLoss, True)):
             def fwd():
                 with torch.no_grad():
                     return fn.apply(x, w, t, -1, 4096, False)

@@ -309,9 +309,10 @@ class _QLoRALinearFn(torch.autograd.Function):
     (M >= DENSE_M, bf16): HIP decode into the scratch + the tile GEMM.  d(ea), d(eb): the streaming rank-r kernels."""
 
     @staticmethod
-    def forward(ctx, x2, ea, eb, wq, scales, bias, N, K, wdense=None):
+    def forward(ctx, x2, ea, eb, wq, scales, bias, N, K, wdense=None, owner=None):
         M = x2.shape[0]
         ctx.scales = scales
+        ctx.owner = owner
         dt = _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32
         ctx.dense = dt == _lib.BF16 and (M >= DENSE_M or wdense is not None)
         ctx.wdense = wdense
@@ -352,7 +353,8 @@ class _QLoRALinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = d_ea = d_eb = None
         if ctx.needs_input_grad[0] and ctx.hip_gemm:
-            dx = hip_gemm(dy, _dense_weight_t(wq, scales, N, K), None, None, None, None, K)
+            wt = _resident_weight(ctx.owner, True) if M >= DENSE_M else None
+            dx = hip_gemm(dy, wt if wt is not None else _dense_weight_t(wq, scales, N, K), None, None, None, None, K)
         elif ctx.needs_input_grad[0] and ctx.dense:
             dx = dy @ (ctx.wdense if ctx.wdense is not None else _dense_weight(wq, scales, N, K))
         elif ctx.needs_input_grad[0]:
@@ -380,7 +382,7 @@ class _QLoRALinearFn(torch.autograd.Function):
                     d_ea = dyb @ eb                   # shapes the thin kernels do not take: tensor ops
                 if ctx.needs_input_grad[2]:
                     d_eb = dyb.t() @ ea
-        return dx, d_ea, d_eb, None, None, None, None, None, None
+        return dx, d_ea, d_eb, None, None, None, None, None, None, None
 
 
 # ---- rank-r products around the library GEMM (csrc/lora_thin.hip) ------------------------------------------------
@@ -539,6 +541,40 @@ def hip_gemm(x2: torch.Tensor, w: torch.Tensor, scales, bias, ea, eb, N: int) ->
 _dense_scratch_t = {}
 
 
+# Decoded copies of FROZEN NF4 weights kept across the forward and backward passes of a step (and across steps): W (N, K) for the
+# product and W^T (K, N) for dx, decoded once per layer by the HIP kernels instead of once per layer per pass (2 x ~25 us per
+# linear per step at Llama-2-7B widths).  Kept per module up to a global budget -- the bf16 copies of a whole 7B model are 26 GB
+# of the MI355X's 288 GB; beyond the budget a layer falls back to the per-call scratch decode.  Keyed by the identity of the code
+# tensor, so quantize_base / merge / load / .to() start over.  FASTMAX_DENSE_RESIDENT_BYTES=0 turns it off.
+RESIDENT_BYTES = int(os.environ.get("FASTMAX_DENSE_RESIDENT_BYTES", str(64 << 30)))
+_resident = weakref.WeakKeyDictionary()           # NF4Linear -> {"tag": ..., "w": tensor | None, "wt": tensor | None}
+_resident_used = [0]
+
+
+def _resident_weight(base, transposed: bool):
+    """the kept bf16 W (or W^T) of an NF4Linear, decoding it on first use; None when the budget is spent or residency is off"""
+    if RESIDENT_BYTES <= 0 or base is None:
+        return None
+    wq = base.weight
+    tag = (id(wq), wq.data_ptr(), wq._version, wq.device)
+    ent = _resident.get(base)
+    if ent is None or ent["tag"] != tag:
+        if ent is not None:
+            _resident_used[0] -= sum(t.numel() * 2 for t in (ent["w"], ent["wt"]) if t is not None)
+        ent = {"tag": tag, "w": None, "wt": None}
+        _resident[base] = ent
+    key = "wt" if transposed else "w"
+    if ent[key] is None:
+        N, K = base.out_features, base.in_features
+        if _resident_used[0] + N * K * 2 > RESIDENT_BYTES:
+            return None
+        scales = scales_of(base)
+        src = _dense_weight_t(wq.data, scales, N, K) if transposed else _dense_weight(wq.data, scales, N, K)
+        ent[key] = src.clone()
+        _resident_used[0] += N * K * 2
+    return ent[key]
+
+
 def _dense_weight_t(wq, scales, N, K):
     """bf16 (K, N) = W^T decoded from the codes of W (N, K) into a per-(device, stream) scratch (the operand of dx = dy W)"""
     key = (wq.device, torch.cuda.current_stream(wq.device).cuda_stream)
@@ -619,6 +655,7 @@ class _QLoRAGemmFn(torch.autograd.Function):
         ctx.rope = rope
         ctx.dense_base = wdense if wq is None else None           # a dense frozen base: its own weight serves dx
         ctx.dense_owner = owner if wq is None else None           # ... and its layer keeps the transposed copy
+        ctx.nf4_owner = owner if wq is not None else None         # an NF4 layer: its resident W^T (if any) serves dx
         if rope is not None:
             cos32, sin32, B, T, G, qpk, hs, rope_n, tables16, expand = rope
             w = wdense if wdense is not None else _dense_weight(wq, scales, N, K)
@@ -652,7 +689,9 @@ class _QLoRAGemmFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx = dy W + d_ea abt: the GEMM over n with W^T as its weight operand and the LoRA step (d_ea, abt^T)
             if ctx.dense_base is None:
-                wt = _dense_weight_t(wq, ctx.scales, N, K)
+                wt = _resident_weight(ctx.nf4_owner, True)
+                if wt is None:
+                    wt = _dense_weight_t(wq, ctx.scales, N, K)
             else:
                 wt = _frozen_transpose(ctx.dense_owner) if ctx.dense_owner is not None else ctx.dense_base.t().contiguous()
             if ctx.drop is None:
@@ -734,9 +773,13 @@ def qlora_linear_thin(x, base: "NF4Linear", A, ebt, rope=None, drop_p: float = 0
         return y if rope is not None else y.reshape(*x.shape[:-1], N)
     scales = scales_of(base)
     if QLORA_ROUTE != "library" and N % 64 == 0 and K % 64 == 0:
+        fused = QLORA_ROUTE == "fused" and rope is None
+        wd = base._dense_cache
+        if wd is None and not fused:
+            wd = _resident_weight(base, False)                       # decoded once per layer, not once per pass
         if rope is not None:
-            return _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, False, rope, None, drop_p)
-        y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, base._dense_cache, QLORA_ROUTE == "fused", None, None, drop_p)
+            return _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, wd, False, rope, base, drop_p)
+        y = _QLoRAGemmFn.apply(x2, A, ebt, base.weight.data, scales, bias, N, K, wd, fused, None, base, drop_p)
     else:
         if drop_p > 0.0:
             raise NotImplementedError("LoRA dropout on the many-rows route needs FASTMAX_QLORA_ROUTE=gemm (the default) or fused")
@@ -772,7 +815,10 @@ def qlora_linear(x, base: NF4Linear, ea, eb):
     bias = None if base.bias is None else base.bias.data
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, scales_of(base), bias, N, K, base._dense_cache)
+    wd = base._dense_cache
+    if wd is None and cdt == torch.bfloat16 and x2.shape[0] >= DENSE_M:
+        wd = _resident_weight(base, False)                       # training rows: the decoded weight stays (budgeted)
+    y = _QLoRALinearFn.apply(x2, ea, eb, base.weight.data, scales_of(base), bias, N, K, wd, base)
     return y.reshape(*x.shape[:-1], N).to(x.dtype)
 
 

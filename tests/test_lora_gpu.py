@@ -556,3 +556,46 @@ def test_dense_base_with_a_trainable_bias_keeps_its_gradient():
     layer(x).sum().backward()
     assert lora._frozen_wt[layer.linear][1] is not wt
     assert not torch.equal(x.grad, first)
+
+
+@pytest.mark.gpu
+def test_decoded_weights_stay_resident_across_passes(monkeypatch):
+    """the training route decodes a frozen NF4 weight (and its transpose, for dx) ONCE per layer and keeps both within
+    FASTMAX_DENSE_RESIDENT_BYTES: same results as the per-call decode, entries equal to the codec's values, a re-quantised
+    layer starts over, and a zero budget falls back to the scratch decode"""
+    from fastmax_experiments_amd import lora
+    torch.manual_seed(3)
+    layer = lora.LoRALinear(256, 384, r=8, lora_alpha=16, bias=True)
+    torch.nn.init.normal_(layer.lora_B, std=0.05)
+    layer.quantize_base().cuda().to(torch.bfloat16)
+    lora.mark_only_lora_as_trainable(layer)
+    x = torch.randn(2304, 256, device="cuda", dtype=torch.bfloat16)
+    gy = torch.randn(2304, 384, device="cuda", dtype=torch.bfloat16)
+
+    def run():
+        xa = x.clone().requires_grad_(True)
+        y = layer(xa)
+        y.backward(gy)
+        out = (y.detach().clone(), xa.grad.clone(), layer.lora_A.grad.clone(), layer.lora_B.grad.clone())
+        layer.lora_A.grad = layer.lora_B.grad = None
+        return out
+
+    monkeypatch.setattr(lora, "RESIDENT_BYTES", 0)
+    want = run()
+    assert layer.linear not in lora._resident or lora._resident[layer.linear]["w"] is None
+    monkeypatch.setattr(lora, "RESIDENT_BYTES", 1 << 30)
+    got = run()
+    ent = lora._resident[layer.linear]
+    assert ent["w"] is not None and ent["wt"] is not None
+    assert torch.equal(ent["w"], layer.linear.dequantize(torch.bfloat16)) and torch.equal(ent["wt"], ent["w"].t())
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    w_ptr = ent["w"].data_ptr()
+    run()
+    assert lora._resident[layer.linear]["w"].data_ptr() == w_ptr            # not decoded again
+    with torch.no_grad():
+        layer.lora_B.mul_(2.0)
+    layer.merge()                                                            # new codes: the resident copies are stale
+    layer.merged = False
+    run()
+    assert not torch.equal(lora._resident[layer.linear]["w"], ent["w"])

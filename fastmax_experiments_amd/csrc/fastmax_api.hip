@@ -340,4 +340,40 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
     return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, q_inv_norm, k_inv_norm) : launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }
 
+// fastmax_hack.py:36-60 (masked branch) in ONE call: statistics + scan.  With the sequence split the statistics ride on the
+// split's state pass (K is read there anyway, the state is linear in K's scale; Q's words come from extra blocks of the same
+// launch); otherwise they are the paired statistics pass.  q_inv_norm / k_inv_norm (B*H floats each) are OUTPUTS here.
+// workspace = [forward workspace | statistic words].
+static size_t linearmax_stats_bytes(int B, int H, int N) {
+    const size_t per_head = (size_t)((N + 255) / 256) > 32 ? (size_t)((N + 255) / 256) : 32;
+    return sizeof(unsigned int) * 2 * (size_t)B * H * per_head;
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t fastmax_hip_linearmax_forward_auto_workspace(const fastmax_problem* prob) {
+    if (validate(prob)) return 0;
+    return align256(fastmax_hip_forward_workspace(prob)) + linearmax_stats_bytes(prob->B, prob->H, prob->Nq);
+}
+
+int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                                       const int64_t* k_strides, const void* v, const int64_t* v_strides, float* q_inv_norm,
+                                       float* k_inv_norm, void* o, float* g, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    int rc = validate(prob);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides || !q_inv_norm || !k_inv_norm) return FASTMAX_E_NULL;
+    if (!mfma_gen_supported(*prob, true) && !mfma_d128_2p_supported(*prob)) return FASTMAX_E_BAD_SHAPE;
+    if ((int64_t)prob->B * prob->H > 65535) return FASTMAX_E_BAD_SHAPE;
+    if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) &&
+          aligned16(v, v_strides, prob->in_dtype)) || (reinterpret_cast<uintptr_t>(o) & 15))
+        return FASTMAX_E_ALIGNMENT;
+    const size_t fwd_bytes = align256(fastmax_hip_forward_workspace(prob));
+    if (!workspace || workspace_bytes < fwd_bytes + linearmax_stats_bytes(prob->B, prob->H, prob->Nq)) return FASTMAX_E_WORKSPACE;
+    const LinearmaxStats stats{q_inv_norm, k_inv_norm, reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + fwd_bytes)};
+    FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, fwd_bytes,
+              reinterpret_cast<hipStream_t>(stream), &stats};
+    if (mfma_d128_2p_supported(*prob)) return launch_fwd_mfma_d128_2p(a, q_inv_norm, k_inv_norm);
+    return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, q_inv_norm, k_inv_norm) : launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
+}
+
 }  // extern "C"

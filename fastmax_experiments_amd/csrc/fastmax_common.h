@@ -75,6 +75,12 @@ template <int P> __device__ __forceinline__ float poly_fprime(float s) {
 
 // ---- host-side launchers implemented in the .hip files ------------------------------
 namespace fastmax {
+// linearmax forward whose statistics are still to be computed (fastmax_hip_linearmax_forward_auto): the launcher fills inv_q /
+// inv_k (B*H floats each) before its main kernel reads them; partials = scratch words (linearmax_stats_words(B, H, N))
+struct LinearmaxStats {
+    float *inv_q, *inv_k;
+    unsigned int* partials;
+};
 struct FwdArgs {
     fastmax_problem prob;
     const void *q, *k, *v;
@@ -84,6 +90,7 @@ struct FwdArgs {
     void* workspace;
     size_t workspace_bytes;
     hipStream_t stream;
+    const LinearmaxStats* stats = nullptr;
 };
 struct BwdArgs {
     fastmax_problem prob;
@@ -132,6 +139,7 @@ struct SplitPlan { int nseg, cps; };
 SplitPlan split_plan(const fastmax_problem& p);
 size_t split_workspace_bytes(const fastmax_problem& p, int dp);
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
+int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp);
 int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);
 bool mfma_d128_2p_supported(const fastmax_problem& p);
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,

@@ -304,7 +304,10 @@ int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* 
     const SplitPlan plan = split_plan(a.prob);
     if (plan.nseg > 1) {
         if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, 128)) return FASTMAX_E_WORKSPACE;
-        const int rc = launch_split_states(a, plan, 128, kscale);
+        const int rc = a.stats ? linearmax_stats_and_states(a, plan, 128) : launch_split_states(a, plan, 128, kscale);
+        if (rc) return rc;
+    } else if (a.stats) {
+        const int rc = linearmax_stats_and_states(a, plan, 128);
         if (rc) return rc;
     }
     D128Params prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, qscale, kscale, a.prob.H, a.prob.Nq, a.prob.D, a.prob.out_dtype,

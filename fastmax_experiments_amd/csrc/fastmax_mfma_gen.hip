@@ -306,7 +306,10 @@ int launch_fwd_mfma_gen(const FwdArgs& a, const float* qscale, const float* ksca
     const int dp = a.prob.D <= 64 ? 64 : 128;
     if (plan.nseg > 1) {
         if (!a.workspace || a.workspace_bytes < split_workspace_bytes(a.prob, dp)) return FASTMAX_E_WORKSPACE;
-        const int rc = launch_split_states(a, plan, dp, kscale);
+        const int rc = a.stats ? linearmax_stats_and_states(a, plan, dp) : launch_split_states(a, plan, dp, kscale);
+        if (rc) return rc;
+    } else if (a.stats) {
+        const int rc = linearmax_stats_and_states(a, plan, dp);
         if (rc) return rc;
     }
     GenParams prm{a.q, a.k, a.v, a.qs, a.ks, a.vs, a.o, a.g, qscale, kscale, a.prob.H, a.prob.Nq, a.prob.D,

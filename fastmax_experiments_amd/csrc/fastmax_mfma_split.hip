@@ -20,13 +20,20 @@ struct StateParams {
     int H, N, D, nseg, cps;
     const float *g, *c;       // RS (reverse states for the backward): k = q, v = grad_o, rows of v scaled by w_i = 1/g_i,
                               // "ksum" weighted by e_i = -w_i c_i
+    // NORM = 2 (the linearmax statistics ride on this pass): K rows are centred but NOT yet scaled (the state is linear in K, so
+    // the prefix pass applies the scale), every block leaves max ||row - mean||^2 of its rows in partials[which][bh][seg]
+    const void* q;
+    Strides3 qs;
+    unsigned int* partials;
 };
 
 // RS = false: forward states of segments 0 .. nseg-2 (record seg).  RS = true: the reverse-scan states of the p=1 backward
 // (fastmax_mfma_bwd_lin.hip) of segments 1 .. nseg-1 (record seg-1): R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e.
 // block = 4 DP threads: one wave per 16-column slab of the state (DP / 16 waves; round 3: eight waves at D = 128 instead of four
 // with two slabs each -- the pass is latency-bound, one workgroup per CU)
-template <int DP, typename TIN, bool NORM, bool RS = false>
+// NORM = 2: grid.x = 2 nseg -- blocks 0 .. nseg-2 as above + the statistic of their K rows, block nseg-1 the statistic of K's last
+// segment alone, blocks nseg .. 2 nseg-1 the statistic of the Q rows of segment x - nseg (no images, no barriers, no MFMA)
+template <int DP, typename TIN, int NORM, bool RS = false>
 __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int NT = 4 * DP;
@@ -39,25 +46,30 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int seg = blockIdx.x + (RS ? 1 : 0), bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const bool statq = NORM == 2 && (int)blockIdx.x >= prm.nseg;            // block-uniform
+    const bool maxonly = NORM == 2 && (int)blockIdx.x >= prm.nseg - 1;
+    const int seg = NORM == 2 ? (int)blockIdx.x % prm.nseg : (int)blockIdx.x + (RS ? 1 : 0);
     const int N = prm.N, D = prm.D;
-    const TIN* kb = reinterpret_cast<const TIN*>(prm.k) + (int64_t)b * prm.ks.sb + (int64_t)h * prm.ks.sh;
+    const Strides3 kst = statq ? prm.qs : prm.ks;
+    const TIN* kb = reinterpret_cast<const TIN*>(statq ? prm.q : prm.k) + (int64_t)b * kst.sb + (int64_t)h * kst.sh;
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
     const int srow = tid / COLS, scol = tid % COLS;
     const bool colok = scol * EPL < D;
     float ksc = 1.f;
-    if constexpr (NORM) ksc = prm.kscale[bh];
+    if constexpr (NORM == 1) ksc = prm.kscale[bh];
     const float ksc_c = colok ? ksc : 0.f;
     const float invD = 1.0f / (float)D;
     const int nchunks = (N + C - 1) / C;
     const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
 
     u32x4 rk[NPASS], rv[NPASS];
-    const TileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    const TileLoader<TIN, NPASS, RPP> kload(kb, kst.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
         kload.load(n0 / C, rk);
-        vload.load(n0 / C, rv);
+        if (!maxonly) vload.load(n0 / C, rv);
     };
+    float best = 0.f;
     f32x4 s2acc[NSL][MT];
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl)
@@ -68,7 +80,34 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     for (int e = 0; e < EPL; ++e) { ck[e] = 0.f; cv[e] = 0.f; }
 
     issue(c_begin * C);
-    for (int c = c_begin; c < c_end; ++c) {
+    if constexpr (NORM == 2) {
+        if (maxonly) {
+            // statistic only: the rows of one chunk at a time, the next chunk's loads in flight
+            for (int c = c_begin; c < c_end; ++c) {
+                u32x4 cur[NPASS];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) cur[ps] = rk[ps];
+                if (c + 1 < c_end) issue((c + 1) * C);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    float xk[EPL];
+                    piece_to_float<TIN>(cur[ps], xk);
+                    float sk = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) sk += xk[e];
+                    const float nmk = -rowgroup_allsum<COLS>(sk) * invD * ksc_c;
+                    float nn = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const float xc = fmaf(xk[e], ksc_c, nmk);
+                        nn = fmaf(xc, xc, nn);
+                    }
+                    best = fmaxf(best, rowgroup_allsum<COLS>(nn));
+                }
+            }
+        }
+    }
+    for (int c = maxonly ? c_end : c_begin; c < c_end; ++c) {
         const int n0 = c * C;
         __syncthreads();                                           // previous chunk's images consumed
 #pragma unroll
@@ -97,6 +136,12 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
                 const float nmk = -rowgroup_allsum<COLS>(sk) * invD * ksc_c;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) xk[e] = fmaf(xk[e], ksc_c, nmk);
+                if constexpr (NORM == 2) {
+                    float nn = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) nn = fmaf(xk[e], xk[e], nn);
+                    best = fmaxf(best, rowgroup_allsum<COLS>(nn));
+                }
                 stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
             } else {
                 stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
@@ -123,6 +168,19 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
                 }
             }
         }
+    }
+    if constexpr (NORM == 2) {
+        __shared__ float wmax[NT / 64];
+        best = wave_max(best);
+        if (lane == 0) wmax[w] = best;
+        __syncthreads();
+        if (tid == 0) {
+            float m = wmax[0];
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, wmax[i]);
+            prm.partials[((int64_t)(statq ? 0 : 1) * gridDim.y + bh) * prm.nseg + seg] = __float_as_uint(m);
+        }
+        if (maxonly) return;
     }
     // record = [S2 (DP x DP, row-major [m][d]) | S1 (DP) | ksum (DP)]
     float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg - (RS ? 1 : 0)) * (DP * DP + 2 * DP);
@@ -160,6 +218,32 @@ __global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int 
     }
 }
 
+// NORM = 2 companion: folds the statistic words into inv_q, inv_k = 1 / sqrt(max) (block 0 of a head writes them for the main
+// kernel) and runs the inclusive prefix with the K scale applied to what is linear in K: S2 and ksum (S1 = sum v is not)
+__global__ __launch_bounds__(256) void p1_state_prefix_scale_kernel(float* state, int nrec, int rec_floats, int dp,
+                                                                    const unsigned int* partials, int nseg, float* inv_q,
+                                                                    float* inv_k) {
+    const int bh = blockIdx.y, BH = gridDim.y;
+    unsigned int mk = 0u;
+    for (int j = 0; j < nseg; ++j) mk = max(mk, partials[((int64_t)BH + bh) * nseg + j]);
+    const float ksc = 1.0f / sqrtf(__uint_as_float(mk));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned int mq = 0u;
+        for (int j = 0; j < nseg; ++j) mq = max(mq, partials[(int64_t)bh * nseg + j]);
+        inv_q[bh] = 1.0f / sqrtf(__uint_as_float(mq));
+        inv_k[bh] = ksc;
+    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rec_floats) return;
+    const float sc = (e >= dp * dp && e < dp * dp + dp) ? 1.f : ksc;
+    float* base = state + (int64_t)bh * nrec * rec_floats + e;
+    float acc = 0.f;
+    for (int i = 0; i < nrec; ++i) {
+        acc = fmaf(base[(int64_t)i * rec_floats], sc, acc);
+        base[(int64_t)i * rec_floats] = acc;
+    }
+}
+
 SplitPlan split_plan(const fastmax_problem& p) {
     // aim at two workgroups per CU for D <= 64 and one for D > 64 (those kernels hold a 128 x 128 state: one 8-wave
     // workgroup per CU); FASTMAX_SPLIT_TARGET overrides for experiments (measured: 512 is the optimum at D = 64)
@@ -182,8 +266,8 @@ size_t split_workspace_bytes(const fastmax_problem& p, int dp) {
     return sizeof(float) * (size_t)p.B * p.H * (plan.nseg - 1) * ((size_t)dp * dp + 2 * dp);
 }
 
-template <int DP, typename TIN, bool NORM, bool RS = false>
-static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
+template <int DP, typename TIN, int NORM, bool RS = false>
+static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 4 * DP / (DP / EPL);
     constexpr int lds = 2 * NP * 64 * DP * 2 + 2 * RPP * DP * 4;
     auto kern = p1_state_kernel<DP, TIN, NORM, RS>;
@@ -193,43 +277,74 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(4 * DP), lds, stream, prm);
     const int rec = DP * DP + 2 * DP;
+    if constexpr (NORM == 2) {
+        hipLaunchKernelGGL(kern, dim3(2 * prm.nseg, BH), dim3(4 * DP), lds, stream, prm);
+        hipLaunchKernelGGL(p1_state_prefix_scale_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1,
+                           rec, DP, prm.partials, prm.nseg, inv_q, inv_k);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(4 * DP), lds, stream, prm);
     // one record per head (two segments) is its own prefix
     if (prm.nseg > 2)
         hipLaunchKernelGGL(p1_state_prefix_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1, rec, RS ? 1 : 0);
     return (int)hipGetLastError();
 }
-template <typename TIN, bool NORM>
-static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream) {
-    if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream);
-    return launch_state_t<128, TIN, NORM>(prm, BH, stream);
+template <typename TIN, int NORM>
+static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr) {
+    if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream, inv_q, inv_k);
+    return launch_state_t<128, TIN, NORM>(prm, BH, stream, inv_q, inv_k);
 }
 
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
                          const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream) {
-    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c};
+    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr};
     const int BH = p.B * p.H;
     switch (p.in_dtype) {
-        case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, false, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
-        case FASTMAX_BF16: return dp == 64 ? launch_state_t<64, bf16_t, false, true>(prm, BH, stream) : launch_state_t<128, bf16_t, false, true>(prm, BH, stream);
-        case FASTMAX_F16: return dp == 64 ? launch_state_t<64, f16_t, false, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+        case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, 0, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+        case FASTMAX_BF16: return dp == 64 ? launch_state_t<64, bf16_t, 0, true>(prm, BH, stream) : launch_state_t<128, bf16_t, 0, true>(prm, BH, stream);
+        case FASTMAX_F16: return dp == 64 ? launch_state_t<64, f16_t, 0, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
     }
     return FASTMAX_E_BAD_DTYPE;
 }
 
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale) {
     StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), kscale, a.prob.H, a.prob.Nq, a.prob.D,
-                    plan.nseg, plan.cps, nullptr, nullptr};
+                    plan.nseg, plan.cps, nullptr, nullptr, nullptr, Strides3{}, nullptr};
     const int BH = a.prob.B * a.prob.H;
     const bool norm = kscale != nullptr;
     switch (a.prob.in_dtype) {
-        case FASTMAX_F32: return norm ? launch_state_d<float, true>(prm, BH, dp, a.stream) : launch_state_d<float, false>(prm, BH, dp, a.stream);
-        case FASTMAX_BF16: return norm ? launch_state_d<bf16_t, true>(prm, BH, dp, a.stream) : launch_state_d<bf16_t, false>(prm, BH, dp, a.stream);
-        case FASTMAX_F16: return norm ? launch_state_d<f16_t, true>(prm, BH, dp, a.stream) : launch_state_d<f16_t, false>(prm, BH, dp, a.stream);
+        case FASTMAX_F32: return norm ? launch_state_d<float, 1>(prm, BH, dp, a.stream) : launch_state_d<float, 0>(prm, BH, dp, a.stream);
+        case FASTMAX_BF16: return norm ? launch_state_d<bf16_t, 1>(prm, BH, dp, a.stream) : launch_state_d<bf16_t, 0>(prm, BH, dp, a.stream);
+        case FASTMAX_F16: return norm ? launch_state_d<f16_t, 1>(prm, BH, dp, a.stream) : launch_state_d<f16_t, 0>(prm, BH, dp, a.stream);
     }
     return FASTMAX_E_BAD_DTYPE;
+}
+
+// linearmax with the statistics not computed yet (FwdArgs::stats): one launch leaves the segment states of the UNSCALED centred K
+// and the statistic words of Q and K, the prefix pass turns the words into inv_q / inv_k and scales the records
+int launch_split_states_stats(const FwdArgs& a, const SplitPlan& plan, int dp) {
+    const LinearmaxStats& st = *a.stats;
+    StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), nullptr, a.prob.H, a.prob.Nq, a.prob.D,
+                    plan.nseg, plan.cps, nullptr, nullptr, a.q, a.qs, st.partials};
+    const int BH = a.prob.B * a.prob.H;
+    if (BH > 65535) return FASTMAX_E_BAD_SHAPE;
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: return launch_state_d<float, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
+        case FASTMAX_BF16: return launch_state_d<bf16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
+        case FASTMAX_F16: return launch_state_d<f16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
+// statistics for a linearmax forward whose launcher found them missing: with the sequence split they ride on the state pass
+// (above), without it they are the paired statistics pass.  Returns 0 and leaves inv_q / inv_k valid for the launches after it.
+int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp) {
+    const LinearmaxStats& st = *a.stats;
+    if (plan.nseg > 1) return launch_split_states_stats(a, plan, dp);
+    return launch_normalize_stats2(a.q, a.qs, a.k, a.ks, a.prob.in_dtype, st.inv_q, st.inv_k, a.prob.B, a.prob.H, a.prob.Nq, a.prob.D,
+                                   st.partials, a.stream);
 }
 
 }  // namespace fastmax

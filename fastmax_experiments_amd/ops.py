@@ -206,7 +206,7 @@ def normalize_stats_pair(q, k):
     return qi, ki
 
 
-def linearmax_forward_fused(q, k, v):
+def linearmax_forward_fused(q, k, v, return_stats=False):
     """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
     Returns None when the shape / dtype is not covered (the caller then uses the unfused route)."""
     L = _lib.lib()
@@ -215,17 +215,20 @@ def linearmax_forward_fused(q, k, v):
     if q.dtype not in _DT or D > 128:
         return None
     prob = _problem(q, k, q.dtype, q.dtype, 1, True, 1.0, 0.0)
-    qi, ki = normalize_stats_pair(q, k)
+    if B * H > 65535:
+        return None
+    # statistics + scan in one entry point (with the sequence split the statistics ride on the split's state pass)
+    stats = torch.empty((2, B * H), dtype=torch.float32, device=dev)
     o = torch.empty((B, H, N, D), dtype=q.dtype, device=dev)
-    wsb, wsp = _ws(L.fastmax_hip_forward_workspace(ctypes.byref(prob)), dev)
+    wsb, wsp = _ws(L.fastmax_hip_linearmax_forward_auto_workspace(ctypes.byref(prob)), dev)
     with torch.cuda.device(dev):
-        rc = L.fastmax_hip_linearmax_forward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
-                                             v.data_ptr(), _strides(v), qi.data_ptr(), ki.data_ptr(), o.data_ptr(), None,
-                                             wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
+        rc = L.fastmax_hip_linearmax_forward_auto(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                                  v.data_ptr(), _strides(v), stats[0].data_ptr(), stats[1].data_ptr(), o.data_ptr(),
+                                                  None, wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
     if rc in (-2, -5):          # FASTMAX_E_BAD_SHAPE / _ALIGNMENT: not covered by the fused kernel
         return None
-    _lib.check(rc, "fastmax_hip_linearmax_forward")
-    return o
+    _lib.check(rc, "fastmax_hip_linearmax_forward_auto")
+    return (o, stats[0], stats[1]) if return_stats else o
 
 
 def effective_normalize_term(D, normalize_term, tensors_normalized):

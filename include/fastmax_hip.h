@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 8   /* 8: the lmhead_ce_* and debug_gemm_stamps entry points are gone: the head's two products are plain library GEMMs by decision, see DESIGN.md, and the losing GEMM loop variants were removed; + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: the lmhead_ce_* and debug_gemm_stamps entry points are gone: the head's two products are plain library GEMMs by decision, see DESIGN.md, and the losing GEMM loop variants were removed; + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask, fastmax_hip_linearmax_forward_auto(_workspace); 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -185,6 +185,19 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob,
                                   void* o, float* g,
                                   void* workspace, size_t workspace_bytes, void* stream);
 /*      workspace of the fused call = fastmax_hip_forward_workspace(prob) (sequence-split states)   */
+
+/*      The same with the statistics computed by the call (the whole masked branch of fastmax_hack.py:36-60 in one entry point):
+ *      q_inv_norm / k_inv_norm are OUTPUTS (B*H floats each).  When the sequence split is active the statistics ride on its state
+ *      pass -- K is read there anyway and the state is linear in K's scale, so the prefix pass applies it; Q's statistic comes
+ *      from extra blocks of the same launch -- otherwise they are fastmax_hip_normalize_stats2.                             */
+size_t fastmax_hip_linearmax_forward_auto_workspace(const fastmax_problem* prob);
+int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob,
+                                       const void* q, const int64_t* q_strides,
+                                       const void* k, const int64_t* k_strides,
+                                       const void* v, const int64_t* v_strides,
+                                       float* q_inv_norm, float* k_inv_norm,
+                                       void* o, float* g,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:
  *      qkv (B, T, G, q_per_kv + 2, head_size), the QKV linear's output  ->  q (B, G*q_per_kv, T, head_size),

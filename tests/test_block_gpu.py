@@ -84,7 +84,9 @@ def test_block_forward_at_config_shapes(name, T, alg, quant):
         ref = _reference_block(blk, x, cos, sin)
     assert y.shape == x.shape and y.dtype == torch.bfloat16
     # bf16 activations end to end (three roundings: qkv, attention, proj) against float32 math on the same weights
-    assert rel_err(y.float().cpu().numpy(), ref.cpu().numpy()) < 4e-2
+    err = rel_err(y.float().cpu().numpy(), ref.cpu().numpy())
+    print(f"block forward {name} T={T} {alg}: rel_err {err:.3e}")
+    assert err < 1.5e-2
 
 
 def test_dp_finetune_step_on_gpu():
@@ -313,9 +315,13 @@ def test_qlora_block_gradients_against_dense_fp32():
     Bm = blk.attn.lora_B.detach().float().clone().requires_grad_(True)
     yr = _dense_block_fp32(blk, xr, cos, sin, A, Bm, 2)
     yr.backward(gy.to(torch.bfloat16).float())
-    assert rel_err(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy()) < 3e-2
+    err = rel_err(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy())
+    print(f"block fwd rel_err {err:.3e}")
+    assert err < 1.5e-2
     for got, want, name in ((x.grad, xr.grad, "x"), (blk.attn.lora_A.grad, A.grad, "lora_A"), (blk.attn.lora_B.grad, Bm.grad, "lora_B")):
-        assert rel_err(got.float().cpu().numpy(), want.cpu().numpy()) < 4e-2, name
+        err = rel_err(got.float().cpu().numpy(), want.cpu().numpy())
+        print(f"block grad {name} rel_err {err:.3e}")
+        assert err < 1.5e-2, name
 
 
 def test_bench_dp_step_on_device():

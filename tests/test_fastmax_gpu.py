@@ -341,6 +341,29 @@ def test_sequence_split_for_few_heads(shape, dt, tol):
     assert rel_err(oh.float().cpu().numpy(), rh) < 2 * tol
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2 * TOL_FWD), (torch.bfloat16, 1.6e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("shape", [(1, 2, 4096, 64), (1, 3, 1500, 48), (1, 2, 2100, 128), (1, 1, 8192, 128), (2, 8, 1024, 64), (2, 8, 320, 64)])
+def test_linearmax_statistics_ride_on_the_state_pass(shape, dt, tol):
+    """fastmax_hip_linearmax_forward_auto: with the sequence split the prologue statistics come out of the split's state pass
+    (K's words from the blocks that build the states, Q's from extra blocks of the same launch; the records are scaled by the
+    prefix pass).  The statistics it leaves == the definition (fastmax_hack.py:38-43), the output == the fp64 oracle, also for a
+    K of another magnitude in (B, N, H, D) storage; the last shape is too short for the split (paired statistics pass)."""
+    from fastmax_experiments_amd import ops
+    from oracle import fastmax_oracle as orc
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    q = torch.randn(shape, generator=g).to(dt)
+    k = (torch.randn(shape, generator=g) * 2.3 + 0.4).to(dt)
+    v = torch.randn(shape, generator=g).to(dt)
+    kd = k.cuda().transpose(1, 2).contiguous().transpose(1, 2)
+    o, qi, ki = ops.linearmax_forward_fused(q.cuda(), kd, v.cuda(), return_stats=True)
+    for x, inv in ((q, qi), (k, ki)):
+        xc = x.double() - x.double().mean(-1, keepdim=True)
+        want = (1.0 / xc.norm(dim=-1).amax(-1)).reshape(-1)
+        assert torch.allclose(inv.double().cpu(), want, rtol=3e-6, atol=0.0)
+    ro = orc.linearmax_fwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), chunk=64)
+    assert o.dtype == dt and rel_err(o.float().cpu().numpy(), ro) < tol
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_BWD), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
 @pytest.mark.parametrize("shape", [(2, 3, 640, 64), (1, 2, 1000, 32), (1, 2, 513, 48), (1, 1, 2048, 64), (1, 2, 777, 128), (1, 1, 2100, 128),
                                    (2, 2, 1024, 96)])

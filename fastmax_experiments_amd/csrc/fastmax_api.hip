@@ -345,7 +345,7 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
 // launch); otherwise they are the paired statistics pass.  q_inv_norm / k_inv_norm (B*H floats each) are OUTPUTS here.
 // workspace = [forward workspace | statistic words].
 static size_t linearmax_stats_bytes(int B, int H, int N) {
-    const size_t per_head = (size_t)((N + 255) / 256) > 32 ? (size_t)((N + 255) / 256) : 32;
+    const size_t per_head = (size_t)((N + 255) / 256) + 32;          // statistics-only blocks of 256 rows + one word per segment
     return sizeof(unsigned int) * 2 * (size_t)B * H * per_head;
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

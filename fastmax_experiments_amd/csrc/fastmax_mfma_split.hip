@@ -24,15 +24,25 @@ struct StateParams {
     // the prefix pass applies the scale), every block leaves max ||row - mean||^2 of its rows in partials[which][bh][seg]
     const void* q;
     Strides3 qs;
-    unsigned int* partials;
+    unsigned int* partials;   // [2 (q, k)][B*H][pw]
+    int BH, pw;
 };
+constexpr int STAT_LT = 4;    // chunks (of 64 rows) per statistics-only block
+
+// sum over the COLS consecutive lanes that hold one staged row, in every lane: DPP adds where a row is 8 or 16 lanes
+template <int COLS> __device__ __forceinline__ float rowsum_all(float v) {
+    if constexpr (COLS == 8 || COLS == 16) return rowgroup_allsum_dpp<COLS>(v);
+    else return rowgroup_allsum<COLS>(v);
+}
 
 // RS = false: forward states of segments 0 .. nseg-2 (record seg).  RS = true: the reverse-scan states of the p=1 backward
 // (fastmax_mfma_bwd_lin.hip) of segments 1 .. nseg-1 (record seg-1): R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e.
 // block = 4 DP threads: one wave per 16-column slab of the state (DP / 16 waves; round 3: eight waves at D = 128 instead of four
 // with two slabs each -- the pass is latency-bound, one workgroup per CU)
-// NORM = 2: grid.x = 2 nseg -- blocks 0 .. nseg-2 as above + the statistic of their K rows, block nseg-1 the statistic of K's last
-// segment alone, blocks nseg .. 2 nseg-1 the statistic of the Q rows of segment x - nseg (no images, no barriers, no MFMA)
+// NORM = 2: a 1-D grid.  The first B*H*(nseg-1) blocks are the state blocks above (they run the longest, so they are dispatched
+// first) and also leave the statistic of their K rows; the blocks after them are statistics-only (no images, no barriers, no
+// MFMA): STAT_LT chunks each, all loads issued at once -- per head ceil(nchunks / STAT_LT) blocks for Q, then the blocks that cover
+// K's last segment.  Word j of a head: Q block j | K: segment (j < nseg-1) or last-segment block j - (nseg-1).
 template <int DP, typename TIN, int NORM, bool RS = false>
 __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
@@ -46,10 +56,29 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
-    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
-    const bool statq = NORM == 2 && (int)blockIdx.x >= prm.nseg;            // block-uniform
-    const bool maxonly = NORM == 2 && (int)blockIdx.x >= prm.nseg - 1;
-    const int seg = NORM == 2 ? (int)blockIdx.x % prm.nseg : (int)blockIdx.x + (RS ? 1 : 0);
+    const int nchunks_all = (prm.N + 63) / 64;
+    int bh = blockIdx.y, seg = (int)blockIdx.x + (RS ? 1 : 0);
+    bool statq = false, maxonly = false;                                    // block-uniform
+    int light_c0 = 0, word = 0;
+    if constexpr (NORM == 2) {
+        const int nheavy = prm.BH * (prm.nseg - 1), idx = blockIdx.x;
+        if (idx < nheavy) {
+            bh = idx / (prm.nseg - 1);
+            seg = idx - bh * (prm.nseg - 1);
+            word = seg;
+        } else {
+            const int last_c0 = (prm.nseg - 1) * prm.cps;
+            const int nlq = (nchunks_all + STAT_LT - 1) / STAT_LT, nlk = (nchunks_all - last_c0 + STAT_LT - 1) / STAT_LT;
+            const int li = idx - nheavy;
+            bh = li / (nlq + nlk);
+            const int j = li - bh * (nlq + nlk);
+            maxonly = true;
+            statq = j < nlq;
+            light_c0 = statq ? j * STAT_LT : last_c0 + (j - nlq) * STAT_LT;
+            word = statq ? j : prm.nseg - 1 + (j - nlq);
+        }
+    }
+    const int b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const Strides3 kst = statq ? prm.qs : prm.ks;
     const TIN* kb = reinterpret_cast<const TIN*>(statq ? prm.q : prm.k) + (int64_t)b * kst.sb + (int64_t)h * kst.sh;
@@ -67,7 +96,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     const TileLoader<TIN, NPASS, RPP> kload(kb, kst.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
         kload.load(n0 / C, rk);
-        if (!maxonly) vload.load(n0 / C, rv);
+        vload.load(n0 / C, rv);
     };
     float best = 0.f;
     f32x4 s2acc[NSL][MT];
@@ -79,34 +108,33 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { ck[e] = 0.f; cv[e] = 0.f; }
 
-    issue(c_begin * C);
+    auto rowstat = [&](const u32x4& piece) __attribute__((always_inline)) {
+        float xk[EPL];
+        piece_to_float<TIN>(piece, xk);
+        float sk = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sk += xk[e];
+        const float nmk = -rowsum_all<COLS>(sk) * invD * ksc_c;
+        float nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float xc = fmaf(xk[e], ksc_c, nmk);
+            nn = fmaf(xc, xc, nn);
+        }
+        best = fmaxf(best, rowsum_all<COLS>(nn));
+    };
     if constexpr (NORM == 2) {
         if (maxonly) {
-            // statistic only: the rows of one chunk at a time, the next chunk's loads in flight
-            for (int c = c_begin; c < c_end; ++c) {
-                u32x4 cur[NPASS];
+            u32x4 t[STAT_LT][NPASS];
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) cur[ps] = rk[ps];
-                if (c + 1 < c_end) issue((c + 1) * C);
+            for (int i = 0; i < STAT_LT; ++i) kload.load(light_c0 + i, t[i]);          // tiles past the tensor load as zeros
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    float xk[EPL];
-                    piece_to_float<TIN>(cur[ps], xk);
-                    float sk = 0.f;
+            for (int i = 0; i < STAT_LT; ++i)
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) sk += xk[e];
-                    const float nmk = -rowgroup_allsum<COLS>(sk) * invD * ksc_c;
-                    float nn = 0.f;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        const float xc = fmaf(xk[e], ksc_c, nmk);
-                        nn = fmaf(xc, xc, nn);
-                    }
-                    best = fmaxf(best, rowgroup_allsum<COLS>(nn));
-                }
-            }
+                for (int ps = 0; ps < NPASS; ++ps) rowstat(t[i][ps]);
         }
     }
+    if (!maxonly) issue(c_begin * C);
     for (int c = maxonly ? c_end : c_begin; c < c_end; ++c) {
         const int n0 = c * C;
         __syncthreads();                                           // previous chunk's images consumed
@@ -133,14 +161,14 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) sk += xk[e];
                 // one fma per element; rows past N were loaded as zeros (mean 0), padded columns have a zero scale
-                const float nmk = -rowgroup_allsum<COLS>(sk) * invD * ksc_c;
+                const float nmk = -rowsum_all<COLS>(sk) * invD * ksc_c;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) xk[e] = fmaf(xk[e], ksc_c, nmk);
                 if constexpr (NORM == 2) {
                     float nn = 0.f;
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) nn = fmaf(xk[e], xk[e], nn);
-                    best = fmaxf(best, rowgroup_allsum<COLS>(nn));
+                    best = fmaxf(best, rowsum_all<COLS>(nn));
                 }
                 stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
             } else {
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
             float m = wmax[0];
 #pragma unroll
             for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, wmax[i]);
-            prm.partials[((int64_t)(statq ? 0 : 1) * gridDim.y + bh) * prm.nseg + seg] = __float_as_uint(m);
+            prm.partials[((int64_t)(statq ? 0 : 1) * prm.BH + bh) * prm.pw + word] = __float_as_uint(m);
         }
         if (maxonly) return;
     }
@@ -221,19 +249,26 @@ __global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int 
 // NORM = 2 companion: folds the statistic words into inv_q, inv_k = 1 / sqrt(max) (block 0 of a head writes them for the main
 // kernel) and runs the inclusive prefix with the K scale applied to what is linear in K: S2 and ksum (S1 = sum v is not)
 __global__ __launch_bounds__(256) void p1_state_prefix_scale_kernel(float* state, int nrec, int rec_floats, int dp,
-                                                                    const unsigned int* partials, int nseg, float* inv_q,
-                                                                    float* inv_k) {
-    const int bh = blockIdx.y, BH = gridDim.y;
-    unsigned int mk = 0u;
-    for (int j = 0; j < nseg; ++j) mk = max(mk, partials[((int64_t)BH + bh) * nseg + j]);
-    const float ksc = 1.0f / sqrtf(__uint_as_float(mk));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned int mq = 0u;
-        for (int j = 0; j < nseg; ++j) mq = max(mq, partials[(int64_t)bh * nseg + j]);
-        inv_q[bh] = 1.0f / sqrtf(__uint_as_float(mq));
+                                                                    const unsigned int* partials, int pw, int nq, int nk,
+                                                                    float* inv_q, float* inv_k) {
+    __shared__ float red[8];
+    const int bh = blockIdx.y, BH = gridDim.y, tid = threadIdx.x;
+    // every block of a head folds K's words (a few dozen); block 0 also Q's and writes both for the main kernel
+    unsigned int mk = 0u, mq = 0u;
+    for (int j = tid; j < nk; j += 256) mk = max(mk, partials[((int64_t)BH + bh) * pw + j]);
+    if (blockIdx.x == 0)
+        for (int j = tid; j < nq; j += 256) mq = max(mq, partials[(int64_t)bh * pw + j]);
+    float fk = wave_max(__uint_as_float(mk)), fq = wave_max(__uint_as_float(mq));        // squared norms: non-negative floats
+    if ((tid & 63) == 0) { red[tid >> 6] = fk; red[4 + (tid >> 6)] = fq; }
+    __syncthreads();
+    fk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    fq = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float ksc = 1.0f / sqrtf(fk);
+    if (blockIdx.x == 0 && tid == 0) {
+        inv_q[bh] = 1.0f / sqrtf(fq);
         inv_k[bh] = ksc;
     }
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 256 + tid;
     if (e >= rec_floats) return;
     const float sc = (e >= dp * dp && e < dp * dp + dp) ? 1.f : ksc;
     float* base = state + (int64_t)bh * nrec * rec_floats + e;
@@ -279,9 +314,11 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, fl
     }
     const int rec = DP * DP + 2 * DP;
     if constexpr (NORM == 2) {
-        hipLaunchKernelGGL(kern, dim3(2 * prm.nseg, BH), dim3(4 * DP), lds, stream, prm);
+        const int nchunks = (prm.N + 63) / 64, last_c0 = (prm.nseg - 1) * prm.cps;
+        const int nlq = (nchunks + STAT_LT - 1) / STAT_LT, nlk = (nchunks - last_c0 + STAT_LT - 1) / STAT_LT;
+        hipLaunchKernelGGL(kern, dim3(BH * (prm.nseg - 1 + nlq + nlk)), dim3(4 * DP), lds, stream, prm);
         hipLaunchKernelGGL(p1_state_prefix_scale_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1,
-                           rec, DP, prm.partials, prm.nseg, inv_q, inv_k);
+                           rec, DP, prm.partials, prm.pw, nlq, prm.nseg - 1 + nlk, inv_q, inv_k);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(4 * DP), lds, stream, prm);
@@ -299,7 +336,7 @@ static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t st
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
                          const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream) {
-    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr};
+    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr, 0, 0};
     const int BH = p.B * p.H;
     switch (p.in_dtype) {
         case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, 0, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
@@ -311,7 +348,7 @@ int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 go
 
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale) {
     StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), kscale, a.prob.H, a.prob.Nq, a.prob.D,
-                    plan.nseg, plan.cps, nullptr, nullptr, nullptr, Strides3{}, nullptr};
+                    plan.nseg, plan.cps, nullptr, nullptr, nullptr, Strides3{}, nullptr, 0, 0};
     const int BH = a.prob.B * a.prob.H;
     const bool norm = kscale != nullptr;
     switch (a.prob.in_dtype) {
@@ -327,7 +364,8 @@ int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const f
 int launch_split_states_stats(const FwdArgs& a, const SplitPlan& plan, int dp) {
     const LinearmaxStats& st = *a.stats;
     StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), nullptr, a.prob.H, a.prob.Nq, a.prob.D,
-                    plan.nseg, plan.cps, nullptr, nullptr, a.q, a.qs, st.partials};
+                    plan.nseg, plan.cps, nullptr, nullptr, a.q, a.qs, st.partials, a.prob.B * a.prob.H,
+                    (a.prob.Nq + 255) / 256 + 32};
     const int BH = a.prob.B * a.prob.H;
     if (BH > 65535) return FASTMAX_E_BAD_SHAPE;
     switch (a.prob.in_dtype) {

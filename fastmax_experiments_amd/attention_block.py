@@ -148,9 +148,11 @@ CausalSelfAttention._forward_one_kernel_qkv = _forward_one_kernel_qkv
 CausalSelfAttention.gemm_rope = True
 
 
-# head shapes of the BASELINE.json configs (lit_gpt/config.py:197-205, 1394-1411, 735-747)
+# head shapes of the BASELINE.json configs (lit_gpt/config.py:197-205, 1394-1411, 735-747) and of the reference config with the
+# largest head size (pythia-1b, config.py:246-254: 8 heads of 256)
 CONFIG_SHAPES = {
     "pythia-14m": dict(n_embd=128, n_head=4, n_query_groups=4, head_size=32, rotary_percentage=0.25, bias=True),
     "tiny-llama-1.1b": dict(n_embd=2048, n_head=32, n_query_groups=4, head_size=64, rotary_percentage=1.0, bias=False),
     "Llama-2-7b-hf": dict(n_embd=4096, n_head=32, n_query_groups=32, head_size=128, rotary_percentage=1.0, bias=False),
+    "pythia-1b": dict(n_embd=2048, n_head=8, n_query_groups=8, head_size=256, rotary_percentage=0.25, bias=True),
 }

@@ -85,7 +85,7 @@ class fastattention_einops(torch.autograd.Function):
         # head sizes that are not a whole number of 16-byte pieces would fall onto the vector-ALU kernels (measured 25-70x
         # slower at N = 2048): zero columns change neither q.k nor the populated columns of f(q.k) v, so pad to a multiple of 8
         # (nt keeps the true D) and slice the result
-        Dp = D if D % 8 == 0 else min(128, (D + 7) // 8 * 8)
+        Dp = D if D % 8 == 0 else min(ops.MAX_HEAD_SIZE, (D + 7) // 8 * 8)
         if Dp != D:
             qd, kd, vd = (torch.nn.functional.pad(t, (0, Dp - D)) for t in (qd, kd, vd))
         out_dt = _out_dtype(kdt, causal)

@@ -28,6 +28,11 @@ int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_QUADRATIC) return FASTMAX_PATH_QUADRATIC;
     if (p.path == FASTMAX_PATH_QUADRATIC_MFMA) return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_E_BAD_SHAPE;
     const bool lin = (p.p == 1 && p.causal);
+    // head sizes above 128 (pythia-1b, Gemma, stablelm-3b in lit_gpt/config.py): tile kernels only -- no D x D state is carried
+    if (p.D > 128) {
+        if (p.path == FASTMAX_PATH_RECURRENT || p.path == FASTMAX_PATH_MFMA) return FASTMAX_E_BAD_SHAPE;
+        return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_PATH_QUADRATIC;
+    }
     if (p.path == FASTMAX_PATH_RECURRENT) return lin ? FASTMAX_PATH_RECURRENT : FASTMAX_E_BAD_SHAPE;
     const bool lin_mfma = lin && (mfma_p1_supported(p) || mfma_gen_supported(p, false) || mfma_d128_2p_supported(p));
     if (p.path == FASTMAX_PATH_MFMA) return lin_mfma ? FASTMAX_PATH_MFMA : FASTMAX_E_BAD_SHAPE;
@@ -117,7 +122,7 @@ const char* fastmax_hip_error_string(int code) {
     switch (code) {
         case FASTMAX_OK: return "ok";
         case FASTMAX_E_BAD_P: return "p should be 1 or 2";
-        case FASTMAX_E_BAD_SHAPE: return "bad shape (sizes must be positive, causal needs Nq == Nk, D <= 128) or path not applicable";
+        case FASTMAX_E_BAD_SHAPE: return "bad shape (sizes must be positive, causal needs Nq == Nk, D <= 256) or path not applicable";
         case FASTMAX_E_BAD_DTYPE: return "bad dtype";
         case FASTMAX_E_WORKSPACE: return "workspace missing or too small";
         case FASTMAX_E_ALIGNMENT: return "pointer / stride alignment";
@@ -267,7 +272,7 @@ int fastmax_hip_normalize_cast(const void* x, const int64_t* x_strides, int dtyp
     if (!workspace || workspace_bytes < fastmax_hip_normalize_workspace(B, H)) return FASTMAX_E_WORKSPACE;
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
     if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
-    if (D * es > 512) return FASTMAX_E_BAD_SHAPE;
+    if (D * es > 1024) return FASTMAX_E_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int npart = (N + 255) / 256;
     if (workspace_bytes >= sizeof(unsigned int) * (size_t)B * H * npart) {
@@ -303,7 +308,7 @@ int fastmax_hip_normalize_cast_expand(const void* x, const int64_t* x_strides, i
     if (B <= 0 || G <= 0 || rep <= 0 || N <= 0 || D <= 0 || D > FASTMAX_MAX_D) return FASTMAX_E_BAD_SHAPE;
     if (dtype < 0 || dtype > FASTMAX_F16) return FASTMAX_E_BAD_DTYPE;
     const int es = dtype == FASTMAX_F32 ? 4 : 2;
-    if (D * es > 512) return FASTMAX_E_BAD_SHAPE;
+    if (D * es > 1024) return FASTMAX_E_BAD_SHAPE;
     const int npart = (N + 255) / 256;
     if (!workspace || workspace_bytes < sizeof(unsigned int) * (size_t)B * G * npart) return FASTMAX_E_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -83,7 +83,7 @@ using namespace fastmax;
 extern "C" {
 
 size_t fastmax_hip_decode_state_bytes(int B, int H, int D) {
-    if (B <= 0 || H <= 0 || D <= 0 || D > FASTMAX_MAX_D) return 0;
+    if (B <= 0 || H <= 0 || D <= 0 || D > 128) return 0;                 // the state cache carries a D x D state: D <= 128
     const size_t dp = D <= 64 ? 64 : 128;
     return sizeof(float) * (size_t)B * H * (dp * dp + 2 * dp);
 }
@@ -106,7 +106,7 @@ int fastmax_hip_p1_decode_step(const void* q, const int64_t* q_strides, const vo
                                const int64_t* v_strides, float* state, void* o, int B, int H, int D, int in_dtype,
                                int out_dtype, float a, int64_t count_after, void* stream) {
     if (!q || !k || !v || !state || !o || !q_strides || !k_strides || !v_strides) return FASTMAX_E_NULL;
-    if (B <= 0 || H <= 0 || D <= 0 || D > FASTMAX_MAX_D || count_after <= 0) return FASTMAX_E_BAD_SHAPE;
+    if (B <= 0 || H <= 0 || D <= 0 || D > 128 || count_after <= 0) return FASTMAX_E_BAD_SHAPE;
     const Strides3 qs{q_strides[0], q_strides[1], q_strides[2]}, ks{k_strides[0], k_strides[1], k_strides[2]},
         vs{v_strides[0], v_strides[1], v_strides[2]};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -32,8 +32,11 @@ struct QuadParams {
     float a, g0;
 };
 
+// output columns a block of the vector-ALU tile kernels accumulates (per lane, in registers)
+template <int DMAX> constexpr int acc_cols() { return DMAX > 128 ? 128 : DMAX; }
+
 // ------------------------------------------------------------------------------------------
-// forward, quadratic tiles.  grid = (ceil(Nq/64), B*H), block = 64 (one wave, one query/lane)
+// forward, quadratic tiles.  grid = (ceil(Nq/64), B*H, DMAX / acc_cols), block = 64 (one wave, one query/lane)
 // ------------------------------------------------------------------------------------------
 template <typename T, int DMAX, int P>
 __global__ __launch_bounds__(64) void fwd_quadratic_kernel(QuadParams prm) {
@@ -53,9 +56,14 @@ __global__ __launch_bounds__(64) void fwd_quadratic_kernel(QuadParams prm) {
         if (gi < prm.Nq && m < D) val = prm.a * to_float(row_ptr<T>(prm.q, prm.qs.sb, prm.qs.sh, prm.qs.sn, b, h, gi)[m]);
         q_s[r * QS + m] = val;
     }
-    float acc[DMAX];
+    // DMAX = 256: a block owns DA = 128 output columns (blockIdx.z picks the half; the scores use the whole row) -- a 256-entry
+    // per-lane accumulator array does not survive register allocation intact on this toolchain (16-bit dK came out wrong in
+    // one column), 128 entries is what every smaller head size uses
+    constexpr int DA = acc_cols<DMAX>();
+    const int d0 = blockIdx.z * DA;
+    float acc[DA];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) acc[d] = 0.f;
+    for (int d = 0; d < DA; ++d) acc[d] = 0.f;
     float gsum = 0.f;
     const int jend = prm.causal ? min(prm.Nk, i0 + TQ) : prm.Nk;
     for (int j0 = 0; j0 < jend; j0 += TK) {
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(64) void fwd_quadratic_kernel(QuadParams prm) {
             if (prm.causal && (j0 + jj) > i) pv = 0.f;
             gsum += pv;
 #pragma unroll
-            for (int d = 0; d < DMAX; d += 4) {
-                const float4 vv = *reinterpret_cast<const float4*>(&v_s[jj * DMAX + d]);
+            for (int d = 0; d < DA; d += 4) {
+                const float4 vv = *reinterpret_cast<const float4*>(&v_s[jj * DMAX + d0 + d]);
                 acc[d] = fmaf(pv, vv.x, acc[d]); acc[d + 1] = fmaf(pv, vv.y, acc[d + 1]);
                 acc[d + 2] = fmaf(pv, vv.z, acc[d + 2]); acc[d + 3] = fmaf(pv, vv.w, acc[d + 3]);
             }
@@ -96,12 +104,13 @@ __global__ __launch_bounds__(64) void fwd_quadratic_kernel(QuadParams prm) {
     const float inv = 1.0f / gval;
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q_s[tid * QS + d] = acc[d] * inv;
-    if (i < prm.Nq && prm.g) prm.g[(int64_t)bh * prm.Nq + i] = gval;
+    for (int d = 0; d < DA; ++d) q_s[tid * QS + d0 + d] = acc[d] * inv;
+    if (i < prm.Nq && prm.g && d0 == 0) prm.g[(int64_t)bh * prm.Nq + i] = gval;
     __syncthreads();
     const int nrows = min(TQ, prm.Nq - i0);
-    for (int idx = tid; idx < nrows * D; idx += 64) {
-        const int r = idx / D, d = idx % D;
+    const int dn = min(DA, D - d0);                                // this block's live columns (<= 0: none)
+    for (int idx = tid; idx < nrows * dn; idx += 64) {
+        const int r = idx / dn, d = d0 + idx % dn;
         store_out(prm.o, prm.out_dtype, ((int64_t)bh * prm.Nq + i0 + r) * D + d, q_s[r * QS + d]);
     }
 }
@@ -110,7 +119,16 @@ template <typename T, int DMAX>
 static int launch_fwd_quadratic_t(const FwdArgs& a, const QuadParams& prm) {
     constexpr int TQ = 64, TK = 32, QS = DMAX + 4;
     const size_t lds = sizeof(float) * (TQ * QS + 2 * TK * DMAX);
-    dim3 grid((a.prob.Nq + TQ - 1) / TQ, a.prob.B * a.prob.H), block(64);
+    dim3 grid((a.prob.Nq + TQ - 1) / TQ, a.prob.B * a.prob.H, DMAX / acc_cols<DMAX>()), block(64);
+    if constexpr (DMAX > 128) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_quadratic_kernel<T, DMAX, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_quadratic_kernel<T, DMAX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+    }
     if (a.prob.p == 1)
         hipLaunchKernelGGL((fwd_quadratic_kernel<T, DMAX, 1>), grid, block, lds, a.stream, prm);
     else
@@ -124,7 +142,8 @@ static int launch_fwd_quadratic_d(const FwdArgs& a, const QuadParams& prm) {
     if (D <= 16) return launch_fwd_quadratic_t<T, 16>(a, prm);
     if (D <= 32) return launch_fwd_quadratic_t<T, 32>(a, prm);
     if (D <= 64) return launch_fwd_quadratic_t<T, 64>(a, prm);
-    return launch_fwd_quadratic_t<T, 128>(a, prm);
+    if (D <= 128) return launch_fwd_quadratic_t<T, 128>(a, prm);
+    return launch_fwd_quadratic_t<T, 256>(a, prm);
 }
 
 int launch_fwd_quadratic(const FwdArgs& a) {
@@ -273,10 +292,13 @@ __device__ __forceinline__ float load_any(const void* base, int dtype, int64_t i
     return (float)reinterpret_cast<const _Float16*>(base)[idx];
 }
 
+// rows of the streamed tile: 32, or 8 at DMAX = 256 (two own 64 x 260 float tiles are 130 KB of the 160 KB)
+template <int DMAX> constexpr int bwd_stream_rows() { return DMAX > 128 ? 8 : 32; }
+
 // dQ: one query per lane.  grid = (ceil(Nq/64), B*H), block = 64
 template <typename T, int DMAX, int P>
 __global__ __launch_bounds__(64) void bwd_dq_kernel(BwdParams prm) {
-    constexpr int TQ = 64, TK = 32, QS = DMAX + 4;
+    constexpr int TQ = 64, TK = bwd_stream_rows<DMAX>(), QS = DMAX + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* q_s = smem;                  // [TQ][QS] scaled by a
     float* G_s = q_s + TQ * QS;         // [TQ][QS]
@@ -303,9 +325,11 @@ __global__ __launch_bounds__(64) void bwd_dq_kernel(BwdParams prm) {
             c = fmaf(G_s[tid * QS + d], load_any(prm.o, prm.o_dtype, ((int64_t)bh * prm.Nq + i) * D + d), c);
         prm.c[(int64_t)bh * prm.Nq + i] = c;
     }
-    float acc[DMAX];
+    constexpr int DA = acc_cols<DMAX>();                           // see fwd_quadratic_kernel
+    const int d0 = blockIdx.z * DA;
+    float acc[DA];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) acc[d] = 0.f;
+    for (int d = 0; d < DA; ++d) acc[d] = 0.f;
     const int jend = prm.causal ? min(prm.Nk, i0 + TQ) : prm.Nk;
     for (int j0 = 0; j0 < jend; j0 += TK) {
         __syncthreads();
@@ -334,8 +358,8 @@ __global__ __launch_bounds__(64) void bwd_dq_kernel(BwdParams prm) {
             float dS = (u - c) * w * poly_fprime<P>(s);
             if (prm.causal && (j0 + jj) > i) dS = 0.f;
 #pragma unroll
-            for (int d = 0; d < DMAX; d += 4) {
-                const float4 kk = *reinterpret_cast<const float4*>(&k_s[jj * DMAX + d]);
+            for (int d = 0; d < DA; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(&k_s[jj * DMAX + d0 + d]);
                 acc[d] = fmaf(dS, kk.x, acc[d]); acc[d + 1] = fmaf(dS, kk.y, acc[d + 1]);
                 acc[d + 2] = fmaf(dS, kk.z, acc[d + 2]); acc[d + 3] = fmaf(dS, kk.w, acc[d + 3]);
             }
@@ -343,11 +367,11 @@ __global__ __launch_bounds__(64) void bwd_dq_kernel(BwdParams prm) {
     }
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q_s[tid * QS + d] = acc[d] * prm.a;
+    for (int d = 0; d < DA; ++d) q_s[tid * QS + d0 + d] = acc[d] * prm.a;
     __syncthreads();
-    const int nrows = min(TQ, prm.Nq - i0);
-    for (int idx = tid; idx < nrows * D; idx += 64) {
-        const int r = idx / D, d = idx % D;
+    const int nrows = min(TQ, prm.Nq - i0), dn = min(DA, D - d0);
+    for (int idx = tid; idx < nrows * dn; idx += 64) {
+        const int r = idx / dn, d = d0 + idx % dn;
         store_out(prm.dq, prm.out_dtype, ((int64_t)bh * prm.Nq + i0 + r) * D + d, q_s[r * QS + d]);
     }
 }
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(64) void bwd_dq_kernel(BwdParams prm) {
 // dK (MODE 0) / dV (MODE 1): one key per lane.  grid = (ceil(Nk/64), B*H), block = 64
 template <typename T, int DMAX, int P, int MODE>
 __global__ __launch_bounds__(64) void bwd_dkv_kernel(BwdParams prm) {
-    constexpr int TJ = 64, TI = 32, QS = DMAX + 4;
+    constexpr int TJ = 64, TI = bwd_stream_rows<DMAX>(), QS = DMAX + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* k_s = smem;                  // [TJ][QS] own keys, scaled by a
     float* v_s = k_s + TJ * QS;         // [TJ][QS] own values (dK only)
@@ -376,9 +400,11 @@ __global__ __launch_bounds__(64) void bwd_dkv_kernel(BwdParams prm) {
         k_s[r * QS + m] = kk;
         v_s[r * QS + m] = vv;
     }
-    float acc[DMAX];
+    constexpr int DA = acc_cols<DMAX>();                           // see fwd_quadratic_kernel
+    const int d0 = blockIdx.z * DA;
+    float acc[DA];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) acc[d] = 0.f;
+    for (int d = 0; d < DA; ++d) acc[d] = 0.f;
     const int ibeg = prm.causal ? j0 : 0;          // j0 is a multiple of 64, hence of TI
     for (int i0 = ibeg; i0 < prm.Nq; i0 += TI) {
         __syncthreads();
@@ -417,8 +443,8 @@ __global__ __launch_bounds__(64) void bwd_dkv_kernel(BwdParams prm) {
             if (prm.causal && (i0 + ii) < j) coef = 0.f;
             const float* src = (MODE == 0) ? q_s : G_s;
 #pragma unroll
-            for (int d = 0; d < DMAX; d += 4) {
-                const float4 xx = *reinterpret_cast<const float4*>(&src[ii * DMAX + d]);
+            for (int d = 0; d < DA; d += 4) {
+                const float4 xx = *reinterpret_cast<const float4*>(&src[ii * DMAX + d0 + d]);
                 acc[d] = fmaf(coef, xx.x, acc[d]); acc[d + 1] = fmaf(coef, xx.y, acc[d + 1]);
                 acc[d + 2] = fmaf(coef, xx.z, acc[d + 2]); acc[d + 3] = fmaf(coef, xx.w, acc[d + 3]);
             }
@@ -427,25 +453,36 @@ __global__ __launch_bounds__(64) void bwd_dkv_kernel(BwdParams prm) {
     __syncthreads();
     const float sc = (MODE == 0) ? prm.a : 1.0f;
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) k_s[tid * QS + d] = acc[d] * sc;
+    for (int d = 0; d < DA; ++d) k_s[tid * QS + d0 + d] = acc[d] * sc;
     __syncthreads();
-    const int nrows = min(TJ, prm.Nk - j0);
+    const int nrows = min(TJ, prm.Nk - j0), dn = min(DA, D - d0);
     void* dst = (MODE == 0) ? prm.dk : prm.dv;
-    for (int idx = tid; idx < nrows * D; idx += 64) {
-        const int r = idx / D, d = idx % D;
+    for (int idx = tid; idx < nrows * dn; idx += 64) {
+        const int r = idx / dn, d = d0 + idx % dn;
         store_out(dst, prm.out_dtype, ((int64_t)bh * prm.Nk + j0 + r) * D + d, k_s[r * QS + d]);
     }
 }
 
 template <typename T, int DMAX, int P>
 static int launch_bwd_tp(const BwdArgs& a, const BwdParams& prm) {
-    constexpr int QS = DMAX + 4;
-    const size_t lds_q = sizeof(float) * (2 * 64 * QS + 2 * 32 * DMAX);
-    const size_t lds_kv = sizeof(float) * (2 * 64 * QS + 2 * 32 * DMAX + 64);
+    constexpr int QS = DMAX + 4, TS = bwd_stream_rows<DMAX>();
+    const size_t lds_q = sizeof(float) * (2 * 64 * QS + 2 * TS * DMAX);
+    const size_t lds_kv = sizeof(float) * (2 * 64 * QS + 2 * TS * DMAX + 64);
+    if constexpr (DMAX > 128) {        // above the 64 KB default
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel<T, DMAX, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkv_kernel<T, DMAX, P, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkv_kernel<T, DMAX, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+    }
     const int BH = a.prob.B * a.prob.H;
-    hipLaunchKernelGGL((bwd_dq_kernel<T, DMAX, P>), dim3((a.prob.Nq + 63) / 64, BH), dim3(64), lds_q, a.stream, prm);
-    hipLaunchKernelGGL((bwd_dkv_kernel<T, DMAX, P, 0>), dim3((a.prob.Nk + 63) / 64, BH), dim3(64), lds_kv, a.stream, prm);
-    hipLaunchKernelGGL((bwd_dkv_kernel<T, DMAX, P, 1>), dim3((a.prob.Nk + 63) / 64, BH), dim3(64), lds_kv, a.stream, prm);
+    constexpr int NZ = DMAX / acc_cols<DMAX>();
+    hipLaunchKernelGGL((bwd_dq_kernel<T, DMAX, P>), dim3((a.prob.Nq + 63) / 64, BH, NZ), dim3(64), lds_q, a.stream, prm);
+    hipLaunchKernelGGL((bwd_dkv_kernel<T, DMAX, P, 0>), dim3((a.prob.Nk + 63) / 64, BH, NZ), dim3(64), lds_kv, a.stream, prm);
+    hipLaunchKernelGGL((bwd_dkv_kernel<T, DMAX, P, 1>), dim3((a.prob.Nk + 63) / 64, BH, NZ), dim3(64), lds_kv, a.stream, prm);
     return (int)hipGetLastError();
 }
 template <typename T, int DMAX>
@@ -458,7 +495,8 @@ static int launch_bwd_d(const BwdArgs& a, const BwdParams& prm) {
     if (D <= 16) return launch_bwd_t<T, 16>(a, prm);
     if (D <= 32) return launch_bwd_t<T, 32>(a, prm);
     if (D <= 64) return launch_bwd_t<T, 64>(a, prm);
-    return launch_bwd_t<T, 128>(a, prm);
+    if (D <= 128) return launch_bwd_t<T, 128>(a, prm);
+    return launch_bwd_t<T, 256>(a, prm);
 }
 // c (B,H,Nq) floats; the 32x32-tile kernels add gt = w G (B,H,Nq,D) in the input dtype behind it (fastmax_quad_mfma_bwd.hip)
 size_t quad32_bwd_gt_offset(const fastmax_problem& p) { return (sizeof(float) * (size_t)p.B * p.H * p.Nq + 255) & ~(size_t)255; }
@@ -486,7 +524,7 @@ int launch_bwd_quadratic(const BwdArgs& a) {
 // linearmax prologue (fastmax.py:326-334): one wave per token
 // ------------------------------------------------------------------------------------------
 // max over tokens of the squared centred norm.  One block walks TOK tokens of one head with 16-byte loads:
-// a token row is spread over LPR lanes (LPR = 32 covers D <= 128 in fp32, D <= 256 in 16-bit), the running max
+// a token row is spread over LPR lanes (LPR = 32 covers D <= 128 in fp32, D <= 256 in 16-bit; 64: D <= 256 in fp32), the running max
 // stays in registers and each block issues ONE atomicMax (token-per-wave with an atomic each serialised on
 // the head's word).  Rows must be 16-byte aligned; `vec` = 0 selects the scalar-load form for unaligned views.
 template <typename T, int LPR>
@@ -551,12 +589,17 @@ __global__ __launch_bounds__(256) void normalize_apply_kernel(const void* x, Str
     if (blockIdx.x == 0 && threadIdx.x == 0 && inv_norm) inv_norm[bh] = inv;
     if (n >= N) return;
     const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
-    const float x0 = lane < D ? to_float(row[lane]) : 0.f;
-    const float x1 = lane + 64 < D ? to_float(row[lane + 64]) : 0.f;
-    const float mean = wave_sum(x0 + x1) / (float)D;
+    float xv[4], s = 0.f;                                     // D <= 256: four columns per lane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xv[j] = lane + 64 * j < D ? to_float(row[lane + 64 * j]) : 0.f;
+        s += xv[j];
+    }
+    const float mean = wave_sum(s) / (float)D;
     float* out = y + ((int64_t)bh * N + n) * D;
-    if (lane < D) out[lane] = (x0 - mean) * inv;
-    if (lane + 64 < D) out[lane + 64] = (x1 - mean) * inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < D) out[lane + 64 * j] = (xv[j] - mean) * inv;
 }
 
 static int rows_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
@@ -574,7 +617,8 @@ static void launch_max_lpr(const void* x, Strides3 xs, int B, int H, int N, int 
     if (need <= 4) hipLaunchKernelGGL((normalize_max_kernel<T, 4>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
     else if (need <= 8) hipLaunchKernelGGL((normalize_max_kernel<T, 8>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
     else if (need <= 16) hipLaunchKernelGGL((normalize_max_kernel<T, 16>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
-    else hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
+    else if (need <= 32) hipLaunchKernelGGL((normalize_max_kernel<T, 32>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
+    else hipLaunchKernelGGL((normalize_max_kernel<T, 64>), grid, block, 0, stream, x, xs, H, N, D, maxbits, vec, partial);
 }
 
 // zero the per-head max words with a kernel, not hipMemsetAsync: a memset node inside a captured HIP graph was observed
@@ -712,7 +756,8 @@ static int launch_stats2_t(const void* x0, Strides3 s0, const void* x1, Strides3
     if (need <= 4) hipLaunchKernelGGL((normalize_max2_kernel<T, 4>), grid, block, 0, stream, prm);
     else if (need <= 8) hipLaunchKernelGGL((normalize_max2_kernel<T, 8>), grid, block, 0, stream, prm);
     else if (need <= 16) hipLaunchKernelGGL((normalize_max2_kernel<T, 16>), grid, block, 0, stream, prm);
-    else hipLaunchKernelGGL((normalize_max2_kernel<T, 32>), grid, block, 0, stream, prm);
+    else if (need <= 32) hipLaunchKernelGGL((normalize_max2_kernel<T, 32>), grid, block, 0, stream, prm);
+    else hipLaunchKernelGGL((normalize_max2_kernel<T, 64>), grid, block, 0, stream, prm);
     hipLaunchKernelGGL(normalize_finish_partials_kernel, dim3((2 * B * H + 255) / 256), dim3(256), 0, stream,
                        reinterpret_cast<const unsigned int*>(ws), npart, inv0, inv1, B * H);
     return (int)hipGetLastError();

@@ -30,7 +30,8 @@ template <int DP, int SW = 0> constexpr int img_bytes() { return 64 * img_row_by
 template <int DP, int SW = 0> __device__ __forceinline__ int img_off(int row, int chunk) {
     if constexpr (SW == 0) {
         if constexpr (DP == 64) return row * 128 + (((chunk ^ row) & 7) << 4);
-        else return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+        else if constexpr (DP == 128) return row * 256 + (((chunk ^ (2 * (row & 7))) & 15) << 4);
+        else return row * (2 * DP) + (((chunk ^ (row & 15)) & (DP / 8 - 1)) << 4);     // 512-byte rows (head sizes up to 256)
     } else if constexpr (SW == 3) {
         if constexpr (DP == 64) return row * 128 + (((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 3) & 3))) & 7) << 4);
         else return row * 256 + (((chunk ^ (((row & 3) << 2) | ((row >> 3) & 3))) & 15) << 4);

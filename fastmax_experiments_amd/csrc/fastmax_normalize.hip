@@ -320,13 +320,14 @@ static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
     if ((need) <= 4) { CALL(4); }       \
     else if ((need) <= 8) { CALL(8); }  \
     else if ((need) <= 16) { CALL(16); } \
-    else { CALL(32); }
+    else if ((need) <= 32) { CALL(32); } \
+    else { CALL(64); }
 
 template <typename T>
 static int normalize_cast_t(const void* x, Strides3 xs, void* y, const float* inv_norm, int B, int H, int N, int D, hipStream_t stream,
                             const unsigned int* partials, int npart, float* inv_out, int rep) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
-    if (need > 32) return FASTMAX_E_BAD_SHAPE;
+    if (need > 64) return FASTMAX_E_BAD_SHAPE;
     // 16-byte accesses need whole pieces per row and aligned rows on both sides; otherwise element-wise loads / stores
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(y) & 15);
     // rep > 1: each row is stored rep times, so blocks take ~256 / rep tokens (at least 32) to keep the grid as large
@@ -372,7 +373,7 @@ template <typename T>
 static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const float* inv_norm, void* gx, int B, int H, int N, int D,
                            void* ws, hipStream_t stream, int rep) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
-    if (need > 32) return FASTMAX_E_BAD_SHAPE;
+    if (need > 64) return FASTMAX_E_BAD_SHAPE;
     const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15);
     // rep > 1 (grouped-query form): every row reads rep gradient rows, so blocks take 256 / rep tokens (at least 32); the
     // partial records then number what the expanded tensor would need (the caller sizes the workspace for B, H rep, N)

@@ -11,7 +11,7 @@
 //   P = f(a S) * mask, split hi/lo in registers (accumulator layout = next B operand, permuted k)
 //   (2) O^T += V^T P^T     A = V^T by ds_read_b64_tr_b16 of the row-major V image
 // fp32 / fp16 inputs are carried as bf16 hi + lo parts (3-term products, ~2^-16 relative); bf16 inputs
-// are exact single parts.  Head sizes are padded to DP = 64 or 128 columns inside LDS only.
+// are exact single parts.  Head sizes are padded to DP = 64, 128 or 256 columns inside LDS only.
 #include "fastmax_mfma_common.h"
 
 #include <cstdlib>
@@ -34,13 +34,16 @@ struct QuadMfmaParams {
 // (p=2 bf16 2.23 -> 2.58 ms, fp32 5.47 -> 6.32 ms; only N = 2048 gained, 0.40 -> 0.36 ms), so QG = 1 ships.
 template <int DP, typename TIN, int NPP> constexpr int quad_qg() { return 1; }
 
-// grid = (ceil(Nq/(64 QG)), B*H), block = 256, dynamic LDS = (QG + 2) * NP * 64*DP*2 bytes
+// grid = (ceil(Nq/(64 QG)), B*H), block = 256, dynamic LDS = (QG + 2) * NP * 64*DP*2 bytes.  DP = 256 (head sizes 136 .. 256,
+// e.g. pythia-1b, Gemma: lit_gpt/config.py): the Q image is only read into registers before the first key tile, so it shares
+// its LDS with the K / V images (2 * NP * 64*DP*2 bytes: 64 KB bf16, 128 KB two-part); one workgroup per CU.
 template <int DP, int P, typename TIN, int NPP, int PFD>
-__global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
+__global__ __launch_bounds__(256, (DP == 64 || (DP == 128 && InTraits<TIN>::NP == 1)) ? 2 : 1) void fwd_quad_mfma_kernel(QuadMfmaParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int QG = quad_qg<DP, TIN, NPP>(), QT = 64 * QG;
     constexpr int IMG = 64 * DP * 2, QIMG = QG * IMG;
-    constexpr int QI = 0, KI = NP * QIMG, VI = KI + NP * IMG;
+    constexpr int QI = 0, KI = DP > 128 ? 0 : NP * QIMG, VI = KI + NP * IMG;
+    static_assert(DP <= 128 || QG == 1, "shared Q / K image");
     constexpr int COLS = DP / EPL, RPP = 256 / COLS, NPASS = 64 / RPP;
     constexpr int KS = DP / 32, DT = DP / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) 
 template <int DP, int P, typename TIN, int NPP, int PFD>
 static int launch_quad_pf(const QuadMfmaParams& prm, int B, hipStream_t stream) {
     constexpr int NP = InTraits<TIN>::NP, QG = quad_qg<DP, TIN, NPP>();
-    constexpr int lds = (QG + 2) * NP * 64 * DP * 2;
+    constexpr int lds = (DP > 128 ? 2 : QG + 2) * NP * 64 * DP * 2;
     auto kern = fwd_quad_mfma_kernel<DP, P, TIN, NPP, PFD>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -243,6 +246,7 @@ static int launch_quad_t(const QuadMfmaParams& prm, int B, hipStream_t stream) {
 }
 template <int P, typename TIN>
 static int launch_quad_d(const QuadMfmaParams& prm, int B, hipStream_t stream) {
+    if (prm.D > 128) return launch_quad_t<256, P, TIN>(prm, B, stream);
     return prm.D <= 64 ? launch_quad_t<64, P, TIN>(prm, B, stream) : launch_quad_t<128, P, TIN>(prm, B, stream);
 }
 template <typename TIN>
@@ -255,7 +259,7 @@ bool quad_mfma_supported(const fastmax_problem& p) {
     // a handful of queries against a short key range stays on the vector-ALU tiles; a single new token against a long KV
     // cache (generation, lit_gpt/model.py:464-466) must not: that kernel walks the keys with one query per wave
     // (measured 4.6 ms at N_k = 4096, 46 ms at 16 k; the matrix-core tile with 15 idle query rows takes 0.07 ms)
-    return (p.D % epl) == 0 && p.D <= 128 && (p.Nq >= 16 || p.Nk >= 256);
+    return (p.D % epl) == 0 && p.D <= 256 && (p.Nq >= 16 || p.Nk >= 256);
 }
 
 int launch_fwd_quad_mfma(const FwdArgs& a) {

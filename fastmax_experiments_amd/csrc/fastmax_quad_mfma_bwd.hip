@@ -131,7 +131,7 @@ static void launch_prep(const QuadBwdParams& prm, int BH, hipStream_t stream) {
 
 // ---- dQ: grid = (ceil(Nq/64), B*H), block = 256, LDS = 4*NP*IMG ------------------------------------
 template <int DP, int P, typename TIN>
-__global__ __launch_bounds__(256, (DP == 64 || InTraits<TIN>::NP == 1) ? 2 : 1) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
+__global__ __launch_bounds__(256, (DP == 64 || (DP == 128 && InTraits<TIN>::NP == 1)) ? 2 : 1) void bwd_dq_mfma_kernel(QuadBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int IMG = 64 * DP * 2;
     constexpr int QI = 0, GI = NP * IMG, KI = 2 * NP * IMG, VI = 3 * NP * IMG;
@@ -425,6 +425,10 @@ static int launch_bwd_t(const QuadBwdParams& prm, int B, hipStream_t stream) {
 }
 template <int P, typename TIN>
 static int launch_bwd_d(const QuadBwdParams& prm, int B, hipStream_t stream) {
+    if constexpr (InTraits<TIN>::NP == 1) {
+        // head sizes 136 .. 256 (pythia-1b, Gemma, stablelm-3b): single-part operands only -- four 64 x 256 images are 128 KB
+        if (prm.D > 128) return launch_bwd_t<256, P, TIN>(prm, B, stream);
+    }
     return prm.D <= 64 ? launch_bwd_t<64, P, TIN>(prm, B, stream) : launch_bwd_t<128, P, TIN>(prm, B, stream);
 }
 template <typename TIN>
@@ -434,7 +438,7 @@ static int launch_bwd_p(const QuadBwdParams& prm, int B, int p, hipStream_t stre
 
 bool quad_mfma_bwd_supported(const fastmax_problem& p) {
     const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
-    return (p.D % epl) == 0 && p.D <= 128;
+    return (p.D % epl) == 0 && (p.D <= 128 || (p.D <= 256 && p.in_dtype == FASTMAX_BF16));
 }
 
 // 32x32-tile kernels (fastmax_quad32_bwd.hip) behind the same prep launch

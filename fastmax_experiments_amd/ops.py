@@ -67,6 +67,9 @@ def selected_path(q, k, p, causal, nt=1.0):
 KEEP_STATES = os.environ.get("FASTMAX_KEEP_STATES", "1") != "0"
 
 
+MAX_HEAD_SIZE = 256      # FASTMAX_MAX_D (include/fastmax_hip.h): the largest head size in lit_gpt/config.py (pythia-1b, Gemma-2b)
+
+
 def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True, keep_states=False):
     """q,k,v: device tensors (B,H,N,D) of one dtype in {f32,bf16,f16}. -> (o, g), or (o, g, states) with ``keep_states``:
     the sequence-split prefix states the p=1 masked forward left in its workspace (None when this call has none), for
@@ -76,8 +79,8 @@ def forward(q, k, v, p, causal, nt, g0, out_dtype, need_g=True, keep_states=Fals
         raise ValueError(f"p should be 1 or 2, got p={p}")
     dev = q.device
     B, H, Nq, D = q.shape
-    if D > 128:
-        raise NotImplementedError(f"head size {D} > 128 is not supported by the HIP kernels")
+    if D > MAX_HEAD_SIZE:
+        raise NotImplementedError(f"head size {D} > {MAX_HEAD_SIZE} is not supported by the HIP kernels")
     prob = _problem(q, k, q.dtype, out_dtype, p, causal, nt, g0)
     o = torch.empty((B, H, Nq, D), dtype=out_dtype, device=dev)
     g = torch.empty((B, H, Nq), dtype=torch.float32, device=dev) if need_g else None
@@ -120,8 +123,8 @@ def normalize(x):
     L = _lib.lib()
     dev = x.device
     B, H, N, D = x.shape
-    if D > 128:
-        raise NotImplementedError(f"head size {D} > 128 is not supported by the HIP kernels")
+    if D > MAX_HEAD_SIZE:
+        raise NotImplementedError(f"head size {D} > {MAX_HEAD_SIZE} is not supported by the HIP kernels")
     y = torch.empty((B, H, N, D), dtype=torch.float32, device=dev)
     inv = torch.empty((B, H), dtype=torch.float32, device=dev)
     wsb, wsp = _ws(L.fastmax_hip_normalize_workspace(B, H), dev)

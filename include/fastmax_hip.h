@@ -43,7 +43,7 @@ enum fastmax_error {
     FASTMAX_E_NULL = -6
 };
 
-#define FASTMAX_MAX_D 128
+#define FASTMAX_MAX_D 256   /* 136 .. 256: tile kernels only (matrix cores: forward every dtype, backward bf16; else vector ALU) */
 
 /* Which kernel family a call would use; for tests and the benchmark report. */
 enum fastmax_path {

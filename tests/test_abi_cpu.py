@@ -61,8 +61,12 @@ def test_problem_validation_without_gpu(lib):
     assert lib.fastmax_hip_select_path(ctypes.byref(bad_p)) == -1
     bad_shape = Problem(2, 4, 5, 16, 64, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_AUTO)      # causal, Nq != Nk
     assert lib.fastmax_hip_select_path(ctypes.byref(bad_shape)) == -2
-    big_d = Problem(2, 4, 16, 16, 256, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_AUTO)
-    assert lib.fastmax_hip_select_path(ctypes.byref(big_d)) == -2
+    big_d = Problem(2, 4, 16, 16, 256, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_AUTO)                # head sizes up to 256: tile kernels only
+    assert lib.fastmax_hip_select_path(ctypes.byref(big_d)) == PATH_QUADRATIC_MFMA
+    big_d_scan = Problem(2, 4, 16, 16, 256, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_RECURRENT)
+    assert lib.fastmax_hip_select_path(ctypes.byref(big_d_scan)) == -2
+    too_big_d = Problem(2, 4, 16, 16, 264, 0, 0, 1, 1, 1.0, 1.0, 0.0, PATH_AUTO)
+    assert lib.fastmax_hip_select_path(ctypes.byref(too_big_d)) == -2
     # null pointers are rejected before anything is launched
     assert lib.fastmax_hip_forward(ctypes.byref(ok), None, None, None, None, None, None, None, None, None, 0, None) == -6
     # c w (B,H,Nq) floats, then the 32x32-tile kernels' w G copy (B,H,Nq,D) in the input dtype

@@ -66,6 +66,8 @@ def _reference_block(blk, x, cos, sin):
     ("tiny-llama-1.1b", 2048, "fastmax", True),     # config 3: QLoRA (NF4) + fastmax, seq 2048
     ("Llama-2-7b-hf", 4096, "fastmax", True),       # config 4: QLoRA + fastmax (p=2, D=128), seq 4096
     ("Llama-2-7b-hf", 16384, "linearmax", True),    # config 5: linearmax long context, seq 16384
+    ("pythia-1b", 512, "fastmax", False),           # the largest head size of the reference's configs: 8 heads of 256
+    ("pythia-1b", 512, "linearmax", True),
 ])
 def test_block_forward_at_config_shapes(name, T, alg, quant):
     from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache
@@ -86,7 +88,7 @@ def test_block_forward_at_config_shapes(name, T, alg, quant):
     # bf16 activations end to end (three roundings: qkv, attention, proj) against float32 math on the same weights
     err = rel_err(y.float().cpu().numpy(), ref.cpu().numpy())
     print(f"block forward {name} T={T} {alg}: rel_err {err:.3e}")
-    assert err < 1.5e-2
+    assert err < 1e-2
 
 
 def test_dp_finetune_step_on_gpu():
@@ -317,11 +319,11 @@ def test_qlora_block_gradients_against_dense_fp32():
     yr.backward(gy.to(torch.bfloat16).float())
     err = rel_err(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy())
     print(f"block fwd rel_err {err:.3e}")
-    assert err < 1.5e-2
+    assert err < 1e-2
     for got, want, name in ((x.grad, xr.grad, "x"), (blk.attn.lora_A.grad, A.grad, "lora_A"), (blk.attn.lora_B.grad, Bm.grad, "lora_B")):
         err = rel_err(got.float().cpu().numpy(), want.cpu().numpy())
         print(f"block grad {name} rel_err {err:.3e}")
-        assert err < 1.5e-2, name
+        assert err < 1e-2, name
 
 
 def test_bench_dp_step_on_device():

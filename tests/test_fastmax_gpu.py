@@ -264,6 +264,34 @@ def test_backward_matrix_core_vs_vector_alu_vs_oracle(shape, p, mask, dt, tol):
             assert rel_err(t.grad.float().cpu().numpy(), rr) < tol, (path, n)
 
 
+@pytest.mark.parametrize("dt,tolf,tolb", [(torch.float32, TOL_FWD, TOL_BWD), (torch.bfloat16, 8e-3, 2e-2), (torch.float16, 2e-3, 4e-3)])
+@pytest.mark.parametrize("shape,p,mask", [((1, 2, 300, 256), 2, True), ((2, 1, 130, 192), 2, True), ((1, 2, 257, 136), 1, True),
+                                          ((1, 2, 200, 256), 2, False), ((1, 1, 70, 160), 1, False)])
+def test_head_sizes_above_128(shape, p, mask, dt, tolf, tolb):
+    """head sizes 136 .. 256 (lit_gpt/config.py: pythia-1b and Gemma-2b 256, stablelm-tuned-alpha-3b and Gemma-7b 192): the tile
+    kernels with 256-column images -- matrix cores for the forward (every dtype) and the bf16 backward, the vector-ALU tiles for
+    the fp32 / fp16 backward and on request -- against the C oracle (fp64), forward and gradients"""
+    from attention_mechanisms.fastmax import fastmax
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(shape[2] + shape[3] + p)
+    q, k, v, go = (torch.randn(shape, generator=g).to(dt) for _ in range(4))
+    qn, kn, vn, gn = (t.float().numpy() for t in (q, k, v, go))
+    ro, _ = c_oracle.fwd(qn, kn, vn, mask=mask, p=p)
+    e = c_oracle.bwd(qn, kn, vn, gn, mask=mask, p=p)
+    assert ops.selected_path(q.cuda(), k.cuda(), p, mask) == _lib.PATH_QUADRATIC_MFMA
+    for path in ("auto", "quadratic"):
+        _force(path)
+        qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        o = fastmax(qq, kk, vv, mask=mask, p=p)
+        assert rel_err(o.detach().float().cpu().numpy(), ro) < tolf, path
+        o.backward(go.cuda().to(o.dtype))
+        for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+            assert t.grad.dtype == dt
+            assert rel_err(t.grad.float().cpu().numpy(), rr) < tolb, (path, n)
+    _force("auto")
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_FWD), (torch.bfloat16, 8e-3), (torch.float16, 2e-3)])
 @pytest.mark.parametrize("shape", [(2, 3, 200, 64), (1, 2, 1000, 32), (1, 2, 130, 16), (1, 2, 257, 48), (2, 2, 65, 64),
                                    (1, 2, 300, 128), (1, 2, 129, 96)])
@@ -285,7 +313,7 @@ def test_linear_time_matrix_core_kernel_dtypes_and_head_sizes(shape, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-4), (torch.bfloat16, 1.5e-2), (torch.float16, 3e-3)])
-@pytest.mark.parametrize("shape", [(2, 3, 200, 64), (1, 4, 1024, 32), (1, 2, 333, 128), (1, 2, 70, 80)])
+@pytest.mark.parametrize("shape", [(2, 3, 200, 64), (1, 4, 1024, 32), (1, 2, 333, 128), (1, 2, 70, 80), (1, 2, 200, 256), (1, 2, 130, 192)])
 def test_linearmax_fused_prologue(shape, dt, tol):
     """fastmax_hack masked, forward only: prologue fused into the kernel (where covered) vs the fp64 oracle"""
     from attention_mechanisms.fastmax_hack import fastmax_hack
@@ -679,7 +707,8 @@ print("narrow ok")
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
-@pytest.mark.parametrize("shape", [(2, 3, 300, 64), (1, 2, 1000, 128), (1, 5, 17, 16), (1, 2, 260, 40), (2, 8, 513, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 300, 64), (1, 2, 1000, 128), (1, 5, 17, 16), (1, 2, 260, 40), (2, 8, 513, 32), (1, 2, 300, 256),
+                                   (1, 3, 130, 192)])
 def test_linearmax_prologue_forward_backward_kernels(shape, dt, tol):
     """_NormalizeQK (fastmax_normalize.hip; D=40 in 16-bit takes the float32 kernel + tensor-op backward) against float64
     autograd over the reference's own formulation (fastmax_hack.py:38-43)"""

@@ -60,6 +60,9 @@ def main():
         ("C4 heads fastmax p=1 f32 fwd+bwd (scan backward)", "fastmax", (2, 32, 4096, 128), "f32", 1, "fwd+bwd"),
         ("C5 heads fastmax p=1 f32 16k fwd+bwd (scan backward)", "fastmax", (1, 32, 16384, 128), "f32", 1, "fwd+bwd"),
         ("C5 heads linearmax f32 16k fwd+bwd", "linearmax", (1, 32, 16384, 128), "f32", 1, "fwd+bwd"),
+        ("pythia-1b heads (head size 256) fastmax(p=2)", "fastmax", (8, 8, 2048, 256), "bf16", 2, "fwd"),
+        ("pythia-1b heads (head size 256) fastmax(p=2) fwd+bwd", "fastmax", (8, 8, 2048, 256), "bf16", 2, "fwd+bwd"),
+        ("pythia-1b heads linearmax fwd+bwd", "linearmax", (8, 8, 2048, 256), "bf16", 1, "fwd+bwd"),
     ]
     if quick:
         cases = cases[:4]

@@ -281,10 +281,11 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-# Above this many rows of x the frozen weight is decoded ONCE into a bf16 scratch matrix (HIP kernel) and the product is a
-# plain library GEMM: the fused kernel re-decodes each W tile in every one of the M/128 workgroup rows and is
-# vector-ALU-bound there (measured 0.54-0.72 PF/s against 1.1-1.5 PF/s dense at M = 8k..16k); below it the fused kernel
-# wins on weight bytes (0.5 B/element instead of 2).  288 GB of HBM make the scratch (<= N K 2 bytes, shared by all layers) free.
+# Above this many rows of x the frozen weight is decoded ONCE into dense bf16 (HIP kernel; kept resident across passes within
+# RESIDENT_BYTES, else a per-stream scratch) and the product is the hand-written 256 x 256-tile GEMM of nf4_gemm.hip (route
+# "gemm"; "library" = hipBLASLt for A/B): the 128-tile fused kernel re-decodes each W tile in every one of the M/128 workgroup
+# rows and is vector-ALU-bound there (measured 0.54-0.72 PF/s against 1.1-1.5 PF/s dense at M = 8k..16k); below it the fused
+# kernel wins on weight bytes (0.5 B/element instead of 2).
 DENSE_M = int(os.environ.get("FASTMAX_NF4_DENSE_M", "2048"))
 _dense_scratch = {}
 

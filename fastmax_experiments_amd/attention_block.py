@@ -155,4 +155,5 @@ CONFIG_SHAPES = {
     "tiny-llama-1.1b": dict(n_embd=2048, n_head=32, n_query_groups=4, head_size=64, rotary_percentage=1.0, bias=False),
     "Llama-2-7b-hf": dict(n_embd=4096, n_head=32, n_query_groups=32, head_size=128, rotary_percentage=1.0, bias=False),
     "pythia-1b": dict(n_embd=2048, n_head=8, n_query_groups=8, head_size=256, rotary_percentage=0.25, bias=True),
+    "Gemma-2b": dict(n_embd=2048, n_head=8, n_query_groups=1, head_size=256, rotary_percentage=1.0, bias=False),   # config.py:796-811 (multi-query)
 }

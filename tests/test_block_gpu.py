@@ -68,6 +68,7 @@ def _reference_block(blk, x, cos, sin):
     ("Llama-2-7b-hf", 16384, "linearmax", True),    # config 5: linearmax long context, seq 16384
     ("pythia-1b", 512, "fastmax", False),           # the largest head size of the reference's configs: 8 heads of 256
     ("pythia-1b", 512, "linearmax", True),
+    ("Gemma-2b", 512, "fastmax", True),             # multi-query, head size 256: one K / V head viewed by the 8 query heads
 ])
 def test_block_forward_at_config_shapes(name, T, alg, quant):
     from fastmax_experiments_amd.attention_block import CONFIG_SHAPES, CausalSelfAttention, build_rope_cache

@@ -118,11 +118,12 @@ def test_decode_shapes_matrix_core_tiles():
             # unmasked g carries the constant N_q (fastmax.py:271): with one or three queries g = N_q + a q.ksum can be close
             # to zero and the quotient is ill-conditioned, whatever computes it
             assert rel_err(o.cpu().numpy(), ro) < (TOL_FWD if nq >= 16 else 2e-3)
-    for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 2e-3)):          # 16-bit single-token decode, D = 128
-        q, k, v = (torch.randn(1, 4, n, 128, generator=g).to(dt) for n in (1, 2000, 2000))
-        o = fastmax(q.cuda(), k.cuda(), v.cuda(), mask=False, p=2)
-        ro, _ = orc.fastmax_fwd_dense(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=False, p=2)
-        assert rel_err(o.float().cpu().numpy(), ro) < tol
+    for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 2e-3)):          # 16-bit single-token decode, D = 128 and 256
+        for D in (128, 256):
+            q, k, v = (torch.randn(1, 4, n, D, generator=g).to(dt) for n in (1, 2000, 2000))
+            o = fastmax(q.cuda(), k.cuda(), v.cuda(), mask=False, p=2)
+            ro, _ = orc.fastmax_fwd_dense(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=False, p=2)
+            assert rel_err(o.float().cpu().numpy(), ro) < tol, D
 
 
 def test_c1_baseline_config():
@@ -646,6 +647,8 @@ Q32_CASES = [
     ((1, 8, 256, 256, 64), 2, True), ((2, 3, 300, 300, 64), 2, True), ((1, 2, 333, 333, 128), 2, True),
     ((1, 5, 520, 520, 32), 1, True), ((1, 2, 384, 384, 80), 2, True), ((1, 16, 640, 640, 64), 2, False),
     ((1, 2, 257, 400, 64), 2, False), ((1, 3, 500, 290, 128), 1, False), ((1, 2, 1100, 1100, 64), 2, True),
+    # head sizes above 128: the 16-row tiles with 256-column images (fp32 / fp16 gradients: vector-ALU tiles)
+    ((1, 2, 300, 300, 256), 2, True), ((1, 2, 257, 400, 192), 2, False), ((1, 3, 520, 520, 160), 1, True),
 ]
 
 

@@ -24,6 +24,7 @@ SYMBOLS = ["fastmax_hip_forward_workspace", "fastmax_hip_forward", "fastmax_hip_
            "fastmax_hip_normalize_stats", "fastmax_hip_normalize_cast", "fastmax_hip_normalize_backward_workspace",
            "fastmax_hip_normalize_backward", "fastmax_hip_rope_qkv_split", "fastmax_hip_rope_qkv_split_backward", "fastmax_hip_cross_entropy_forward", "fastmax_hip_cross_entropy_backward",
            "fastmax_hip_linearmax_forward", "fastmax_hip_linearmax_forward_auto", "fastmax_hip_linearmax_forward_auto_workspace",
+           "fastmax_hip_linearmax_backward", "fastmax_hip_linearmax_train_supported",
            "fastmax_hip_nf4_linear_forward", "fastmax_hip_nf4_linear_backward_input", "fastmax_hip_nf4_dequantize",
            "fastmax_hip_lora_down", "fastmax_hip_lora_tn_workspace", "fastmax_hip_lora_tn", "fastmax_hip_lora_up",
            "fastmax_hip_forward_state_bytes", "fastmax_hip_backward_with_states",
@@ -109,6 +110,10 @@ def lib():
     L.fastmax_hip_linearmax_forward_auto.restype = ci
     L.fastmax_hip_linearmax_forward_auto_workspace.argtypes = [pp]
     L.fastmax_hip_linearmax_forward_auto_workspace.restype = sz
+    L.fastmax_hip_linearmax_train_supported.argtypes = [pp]
+    L.fastmax_hip_linearmax_train_supported.restype = ci
+    L.fastmax_hip_linearmax_backward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, i64p, fp, fp, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.fastmax_hip_linearmax_backward.restype = ci
     i64 = ctypes.c_int64
     L.fastmax_hip_decode_state_bytes.argtypes = [ci, ci, ci]
     L.fastmax_hip_decode_state_bytes.restype = sz

@@ -61,6 +61,66 @@ class _NormalizeQK(torch.autograd.Function):
         return gx.to(ctx.in_dtype), None, None
 
 
+FUSED_TRAINING = os.environ.get("FASTMAX_LINEARMAX_FUSED_TRAIN", "1") != "0"
+
+
+class _LinearmaxP1(torch.autograd.Function):
+    """Masked first-order linearmax (fastmax_hack.py:36-60) as ONE autograd node on the raw q, k, v: the prologue is applied by
+    the scan kernels while they stage their tiles, forwards and backwards, so no normalised copy of q or k is written or kept
+    (the two normalize_cast passes and the separate statistics passes of the two-node route disappear); its gradient is the
+    one-pass prologue backward on the scans' dq, dk.  ``rep`` > 1 (grouped-query heads): k holds the G key heads, q and v are
+    (B*G, rep, N, D) (v a stride-0 group view): K is viewed the same way, every query head of a group computes the group's
+    statistics from the same rows, and the prologue backward sums the group's gradients while it reads them."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, rep):
+        q, k, v = (ops._prep(t, t.device) for t in (q, k, v))
+        kv = k
+        if rep > 1:
+            B, G, N, D = k.shape
+            kv = k.view(B * G, 1, N, D).expand(B * G, rep, N, D)
+        r = ops.linearmax_forward_fused(q, kv, v, train=True)
+        if r is None:
+            raise NotImplementedError("fused linearmax training route does not cover this problem")
+        o, g, inv_q, inv_k, states = r
+        ctx.save_for_backward(q, k, v, o, g, inv_q, inv_k)
+        ctx.states, ctx.rep = states, rep
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o, g, inv_q, inv_k = ctx.saved_tensors
+        rep = ctx.rep
+        kv = k
+        if rep > 1:
+            B, G, N, D = k.shape
+            kv = k.view(B * G, 1, N, D).expand(B * G, rep, N, D)
+        go = ops._prep(go.to(q.dtype), q.device)
+        dqn, dkn, dv = ops.linearmax_backward(q, kv, v, o, g, go, inv_q, inv_k, ctx.states)
+        ctx.states = None
+        dq = ops.normalize_backward(q, dqn, inv_q.view(q.shape[0], q.shape[1]), 1)
+        if rep > 1:
+            B, G, N, D = k.shape
+            inv_g = inv_k.view(B * G, rep)[:, 0].contiguous().view(B, G)
+            dk = ops.normalize_backward(k, dkn.view(B, G * rep, N, D), inv_g, rep)
+        else:
+            dk = ops.normalize_backward(k, dkn, inv_k.view(k.shape[0], k.shape[1]), 1)
+        return dq, dk, dv, None
+
+
+def _fused_training_ok(q, k, v, rep=1):
+    """would _LinearmaxP1 serve these tensors?  (device tensors of one kernel dtype, whole 16-byte pieces per row)"""
+    if not FUSED_TRAINING or q.dtype not in _KERNEL_DTYPES or q.device.type != "cuda":
+        return False
+    D = q.shape[-1]
+    if (D * q.element_size()) % 16 or D > 128 or q.shape[0] * q.shape[1] > MAX_HEADS_PER_LAUNCH:
+        return False
+    prob = ops._problem(q, q, q.dtype, q.dtype, 1, True, 1.0, 0.0)
+    import ctypes
+    from .. import _lib
+    return bool(_lib.lib().fastmax_hip_linearmax_train_supported(ctypes.byref(prob)))
+
+
 def fastmax_hack(q, k, v, p=1, mask=True):
     """linearmax (reference: fastmax_hack.py:5)."""
     if q.shape[0] * q.shape[1] > MAX_HEADS_PER_LAUNCH and q.shape[0] > 1:
@@ -80,6 +140,8 @@ def fastmax_hack(q, k, v, p=1, mask=True):
     # training (or shapes the fused kernel does not cover): prologue and attention as separate autograd nodes,
     # both in libfastmax_hip.so; 16-bit inputs keep their dtype between the two, like the reference
     vd = ops._prep(v.to(kdt), dev)
+    if mask and p == 1 and needs_grad and _fused_training_ok(qd, kd, vd):
+        return _LinearmaxP1.apply(qd, kd, vd, 1).to(device=home, dtype=in_dtype)
     qn, kn = _NormalizeQK.apply(qd, 1), _NormalizeQK.apply(kd, 1)
     if not mask:
         # fastmax_hack.py:6-33: first order whatever p is; constant term N_k; result float32 for
@@ -101,6 +163,8 @@ def fastmax_hack_grouped(q, k_groups, v, rep, p=1):
       q, v (B*G, rep, N, D) (v a stride-0 group view) -> K is normalised at its G heads and handed on as a stride-0 view too:
                                                         no per-query-head copy of K or V exists anywhere"""
     views = q.shape[0] == k_groups.shape[0] * k_groups.shape[1] and q.shape[1] == rep and rep > 1
+    if views and p == 1 and _fused_training_ok(q, k_groups, v, rep):
+        return _LinearmaxP1.apply(q, k_groups, v, rep).to(q.dtype)
     qn = _NormalizeQK.apply(q, 1)
     kn = _NormalizeQK.apply(k_groups, rep, views)
     o = fastattention_einops.apply(qn, kn, v, True, 1, True, p, 0.0, False)

@@ -381,4 +381,41 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob, const void* 
     return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, q_inv_norm, k_inv_norm) : launch_fwd_mfma_gen(a, q_inv_norm, k_inv_norm);
 }
 
+// Training route of the same branch: the backward of fastmax_hip_linearmax_forward_auto.  q, k are the RAW tensors and
+// q_inv_norm / k_inv_norm what the forward left; the linear-time scans apply the prologue while staging (as the forward does), so
+// no normalised copy of q or k is ever stored.  dq, dk are the gradients wrt the NORMALISED q, k: the caller finishes with
+// fastmax_hip_normalize_backward(q, dq, q_inv_norm) / (k, dk, k_inv_norm).  fwd_states = the forward's workspace (its prefix
+// states), or null.  FASTMAX_E_BAD_SHAPE where the linear-time backward does not cover the problem (fastmax_hip_linearmax_train_supported).
+int fastmax_hip_linearmax_train_supported(const fastmax_problem* prob) {
+    if (validate(prob)) return 0;
+    if (!(prob->p == 1 && prob->causal) || prob->in_dtype != prob->out_dtype) return 0;
+    return (mfma_gen_supported(*prob, true) && lin_bwd_supported(*prob)) ? 1 : 0;
+}
+
+int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
+                                   const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o, const float* g,
+                                   const void* grad_o, const int64_t* go_strides, const float* q_inv_norm, const float* k_inv_norm,
+                                   void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, const void* fwd_states,
+                                   size_t fwd_state_bytes, void* stream) {
+    int rc = validate(prob);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !g || !grad_o || !dq || !dk || !dv || !q_strides || !k_strides || !v_strides || !go_strides ||
+        !q_inv_norm || !k_inv_norm)
+        return FASTMAX_E_NULL;
+    if (!fastmax_hip_linearmax_train_supported(prob)) return FASTMAX_E_BAD_SHAPE;
+    if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) && aligned16(v, v_strides, prob->in_dtype) &&
+          aligned16(grad_o, go_strides, prob->in_dtype)) ||
+        ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv) | reinterpret_cast<uintptr_t>(o)) & 15))
+        return FASTMAX_E_ALIGNMENT;
+    BwdArgs a{*prob, q, k, v, o, grad_o, g, st(q_strides), st(k_strides), st(v_strides), st(go_strides), dq, dk, dv,
+              workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
+    a.qscale = q_inv_norm;
+    a.kscale = k_inv_norm;
+    const SplitPlan plan = split_plan(*prob);
+    if (fwd_states && plan.nseg > 1 && fwd_state_bytes >= split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128) &&
+        !(reinterpret_cast<uintptr_t>(fwd_states) & 15))
+        a.fwd_states = reinterpret_cast<const float*>(fwd_states);
+    return launch_bwd_lin(a);
+}
+
 }  // extern "C"

@@ -102,6 +102,9 @@ struct BwdArgs {
     size_t workspace_bytes;
     hipStream_t stream;
     const float* fwd_states = nullptr;   // the forward's sequence-split prefix states, when the caller kept them
+    // linearmax training route (fastmax_hip_linearmax_backward): q, k are the RAW tensors; the scan kernels apply the prologue
+    // (x - mean) * scale[bh] while staging, as the fused forward does, and return the gradients wrt the normalised q, k
+    const float *qscale = nullptr, *kscale = nullptr;
 };
 
 int launch_fwd_quadratic(const FwdArgs& a);
@@ -143,7 +146,7 @@ int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp);
 int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);
 bool mfma_d128_2p_supported(const fastmax_problem& p);
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
-                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream);
+                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale = nullptr);
 size_t lin_bwd_workspace(const fastmax_problem& p);
 int launch_fwd_quad_mfma(const FwdArgs& a);
 bool quad_mfma_supported(const fastmax_problem& p);

@@ -26,6 +26,8 @@ struct LinBwdParams {
     // (sums over the earlier segments), segment s of the dK/dV scan from rstate record s (sums over the later ones)
     const float *fstate, *rstate;
     int nseg, cps;
+    // NORM (linearmax training route): q, k are raw; the prologue (x - mean) * scale[bh] is applied while staging
+    const float *qscale, *kscale;
 };
 
 // Stage a wave's 16 x W fp32 accumulator tile (lane = row r, acc[t][reg] = column 16t + 4q4 + reg) through a wave-private
@@ -75,7 +77,7 @@ template <int DP, int SP, int TW> __device__ __forceinline__ void publish_state(
 // NW = 4: wave w owns query tile w and every output column.  NW = 8 (the variants whose LDS footprint allows one workgroup
 // per CU only): wave (wq = w & 3, hf = w >> 2) owns query tile wq and the column half hf of dQ and of the S2 state; the
 // 64 x 64 score-shaped tile is computed by both halves.
-template <int DP, typename TIN, int NW>
+template <int DP, typename TIN, int NW, bool NORM>
 __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
@@ -97,6 +99,9 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
     const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)h * prm.gos.sh;
     const int srow = tid / COLS, scol = tid % COLS;
+    float ksc_c = 0.f;
+    if constexpr (NORM) ksc_c = scol * EPL < D ? prm.kscale[bh] : 0.f;
+    const float invD = 1.0f / (float)D;
 
     // o is contiguous (B,H,N,D) in the input dtype on the masked path (dtype rule Q1)
     const TIN* ob = reinterpret_cast<const TIN*>(prm.o) + (int64_t)bh * N * D;
@@ -154,7 +159,12 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
                 piece_to_float<TIN>(rk[ps], xk);
                 piece_to_float<TIN>(rg[ps], xg);
                 piece_to_float<TIN>(ro[ps], xo);
-                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                if constexpr (NORM) {
+                    normalize_piece<COLS, EPL>(xk, ksc_c, invD);
+                    stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
+                } else {
+                    stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                }
                 stage_piece<DP, TIN>(smem, VI, row, scol, rv[ps]);
                 stage_piece<DP, TIN>(smem, GI, row, scol, rg[ps]);
                 float part = 0.f;
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 // NW = 8: wave (wk = w & 3, hf = w >> 2) owns the 16 keys of tile wk and the column half hf of dK, dV and of the R2 state
-template <int DP, typename TIN, int NW>
+template <int DP, typename TIN, int NW, bool NORM>
 __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
@@ -301,6 +311,12 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
     const TIN* vb = reinterpret_cast<const TIN*>(prm.v) + (int64_t)b * prm.vs.sb + (int64_t)h * prm.vs.sh;
     const TIN* gb = reinterpret_cast<const TIN*>(prm.go) + (int64_t)b * prm.gos.sb + (int64_t)h * prm.gos.sh;
     const int srow = tid / COLS, scol = tid % COLS;
+    float qsc_c = 0.f, ksc_c = 0.f;
+    if constexpr (NORM) {
+        qsc_c = scol * EPL < D ? prm.qscale[bh] : 0.f;
+        ksc_c = scol * EPL < D ? prm.kscale[bh] : 0.f;
+    }
+    const float invD = 1.0f / (float)D;
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS], rg[NPASS];
     float rw[NPASS], rc[NPASS];
@@ -367,10 +383,19 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
                 piece_to_float<TIN>(rq[ps], xq);
                 piece_to_float<TIN>(rg[ps], xg);
                 const float wi = rw[ps], ei = -wi * rc[ps];
+                if constexpr (NORM) {
+                    float xk[EPL];
+                    piece_to_float<TIN>(rk[ps], xk);
+                    normalize_piece<COLS, EPL>(xq, qsc_c, invD);
+                    normalize_piece<COLS, EPL>(xk, ksc_c, invD);
+                    stage_floats<DP, EPL, NP>(smem, QI, row, scol, xq);
+                    stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
+                } else {
+                    stage_piece<DP, TIN>(smem, QI, row, scol, rq[ps]);
+                    stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                }
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { xg[e] *= wi; cg[e] += xg[e]; cq[e] = fmaf(xq[e], ei, cq[e]); }
-                stage_piece<DP, TIN>(smem, QI, row, scol, rq[ps]);
-                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
                 stage_piece<DP, TIN>(smem, VI, row, scol, rv[ps]);
                 stage_floats<DP, EPL, NP>(smem, GI, row, scol, xg);                  // ghat = w G
                 if (scol == 0) reinterpret_cast<float*>(smem + ES)[row] = ei;
@@ -516,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
     }
 }
 
-template <int DP, typename TIN>
+template <int DP, typename TIN, bool NORM>
 static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
@@ -528,8 +553,8 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256;
     static_assert(lds_kv <= 160 * 1024 && lds_q <= 160 * 1024, "LDS budget");
     static_assert(NWKV == 4 || 8 * 2 * 16 * (DP / 2) * 4 <= 4 * NP * IMG, "dK/dV staging areas fit the freed images");
-    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ>;
-    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV>;
+    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM>;
+    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
@@ -541,7 +566,7 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     hipLaunchKernelGGL(kq, dim3(BH * prm.nseg), dim3(64 * NWQ), lds_q, stream, prm);
     if (prm.nseg > 1) {
         const int rc = launch_split_rstates(prm.q, prm.qs, prm.go, prm.gos, prm.g, prm.c, const_cast<float*>(prm.rstate), prob,
-                                            SplitPlan{prm.nseg, prm.cps}, DP, stream);
+                                            SplitPlan{prm.nseg, prm.cps}, DP, stream, prm.qscale);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
@@ -578,19 +603,27 @@ int launch_bwd_lin(const BwdArgs& a) {
     float* rstate = reinterpret_cast<float*>(ws + coff + sbytes);
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                      cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
-                     fstate, rstate, plan.nseg, plan.cps};
+                     fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale};
     const int BH = a.prob.B * a.prob.H;
     if (plan.nseg > 1 && !a.fwd_states) {
         // forward-scan states (sum k v^T, sum k) exactly as the forward's; the reverse-scan states need c_i, which the dQ
         // kernel writes, so they are computed between the two main kernels
         FwdArgs fa{a.prob, a.q, a.k, a.v, a.qs, a.ks, a.vs, nullptr, nullptr, ws + coff, sbytes, a.stream};
-        const int rc = launch_split_states(fa, plan, dp, nullptr);
+        const int rc = launch_split_states(fa, plan, dp, a.kscale);          // kscale: K is raw (linearmax training route)
         if (rc) return rc;
     }
+    if (a.qscale && a.kscale) {
+        switch (a.prob.in_dtype) {
+            case FASTMAX_F32: return launch_lin_bwd_t<64, float, true>(prm, BH, a.stream, a.prob);
+            case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t, true>(prm, BH, a.stream, a.prob) : launch_lin_bwd_t<128, bf16_t, true>(prm, BH, a.stream, a.prob);
+            case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t, true>(prm, BH, a.stream, a.prob);
+        }
+        return FASTMAX_E_BAD_DTYPE;
+    }
     switch (a.prob.in_dtype) {
-        case FASTMAX_F32: return launch_lin_bwd_t<64, float>(prm, BH, a.stream, a.prob);
-        case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t>(prm, BH, a.stream, a.prob) : launch_lin_bwd_t<128, bf16_t>(prm, BH, a.stream, a.prob);
-        case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t>(prm, BH, a.stream, a.prob);
+        case FASTMAX_F32: return launch_lin_bwd_t<64, float, false>(prm, BH, a.stream, a.prob);
+        case FASTMAX_BF16: return a.prob.D <= 64 ? launch_lin_bwd_t<64, bf16_t, false>(prm, BH, a.stream, a.prob) : launch_lin_bwd_t<128, bf16_t, false>(prm, BH, a.stream, a.prob);
+        case FASTMAX_F16: return launch_lin_bwd_t<64, f16_t, false>(prm, BH, a.stream, a.prob);
     }
     return FASTMAX_E_BAD_DTYPE;
 }

@@ -280,6 +280,23 @@ template <int COLS> __device__ __forceinline__ float rowgroup_allsum_dpp(float v
     return v;
 }
 
+// sum over the COLS consecutive lanes that hold one staged row, in every lane: DPP adds where a row is 8 or 16 lanes
+template <int COLS> __device__ __forceinline__ float rowsum_all(float v) {
+    if constexpr (COLS == 8 || COLS == 16) return rowgroup_allsum_dpp<COLS>(v);
+    else return rowgroup_allsum<COLS>(v);
+}
+
+// linearmax prologue on one staged 16-byte piece: (x - mean_D x) * scale as one fma per element (fastmax_hack.py:38-43); `sc_c`
+// is the head's scale, zero on a padded head column; a row past N was loaded as zeros (mean 0 -> 0)
+template <int COLS, int EPL> __device__ __forceinline__ void normalize_piece(float (&x)[EPL], float sc_c, float invD) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += x[e];
+    const float nm = -rowsum_all<COLS>(s) * invD * sc_c;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) x[e] = fmaf(x[e], sc_c, nm);
+}
+
 // Same, but staged in the OUTPUT dtype through a wave-private area, so no workgroup barrier is needed: the 16 image
 // rows a wave alone reads (its query rows) are free once their fragments sit in registers.  area0 / area1 are the
 // two 16-row blocks (2*DP bytes per row) of a two-part image; a 4-byte result row is split across them, a 2-byte

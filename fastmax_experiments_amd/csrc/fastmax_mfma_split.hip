@@ -29,12 +29,6 @@ struct StateParams {
 };
 constexpr int STAT_LT = 4;    // chunks (of 64 rows) per statistics-only block
 
-// sum over the COLS consecutive lanes that hold one staged row, in every lane: DPP adds where a row is 8 or 16 lanes
-template <int COLS> __device__ __forceinline__ float rowsum_all(float v) {
-    if constexpr (COLS == 8 || COLS == 16) return rowgroup_allsum_dpp<COLS>(v);
-    else return rowgroup_allsum<COLS>(v);
-}
-
 // RS = false: forward states of segments 0 .. nseg-2 (record seg).  RS = true: the reverse-scan states of the p=1 backward
 // (fastmax_mfma_bwd_lin.hip) of segments 1 .. nseg-1 (record seg-1): R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e.
 // block = 4 DP threads: one wave per 16-column slab of the state (DP / 16 waves; round 3: eight waves at D = 128 instead of four
@@ -150,7 +144,12 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
                 const float ei = -wi * prm.c[(int64_t)bh * N + gc];
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) xv[e] *= wi;
-                stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                if constexpr (NORM == 1) {                               // linearmax training route: q arrives raw
+                    normalize_piece<COLS, EPL>(xk, ksc_c, invD);
+                    stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
+                } else {
+                    stage_piece<DP, TIN>(smem, KI, row, scol, rk[ps]);
+                }
                 stage_floats<DP, EPL, NP>(smem, VI, row, scol, xv);
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { ck[e] = fmaf(xk[e], ei, ck[e]); cv[e] += xv[e]; }
@@ -335,9 +334,17 @@ static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t st
 
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
-                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream) {
-    StateParams prm{q, go, qs, gos, state, nullptr, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr, 0, 0};
+                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale) {
+    StateParams prm{q, go, qs, gos, state, qscale, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr, 0, 0};
     const int BH = p.B * p.H;
+    if (qscale) {
+        switch (p.in_dtype) {
+            case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, 1, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+            case FASTMAX_BF16: return dp == 64 ? launch_state_t<64, bf16_t, 1, true>(prm, BH, stream) : launch_state_t<128, bf16_t, 1, true>(prm, BH, stream);
+            case FASTMAX_F16: return dp == 64 ? launch_state_t<64, f16_t, 1, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
+        }
+        return FASTMAX_E_BAD_DTYPE;
+    }
     switch (p.in_dtype) {
         case FASTMAX_F32: return dp == 64 ? launch_state_t<64, float, 0, true>(prm, BH, stream) : FASTMAX_E_BAD_SHAPE;
         case FASTMAX_BF16: return dp == 64 ? launch_state_t<64, bf16_t, 0, true>(prm, BH, stream) : launch_state_t<128, bf16_t, 0, true>(prm, BH, stream);

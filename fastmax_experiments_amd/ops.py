@@ -209,9 +209,11 @@ def normalize_stats_pair(q, k):
     return qi, ki
 
 
-def linearmax_forward_fused(q, k, v, return_stats=False):
+def linearmax_forward_fused(q, k, v, return_stats=False, train=False):
     """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
-    Returns None when the shape / dtype is not covered (the caller then uses the unfused route)."""
+    Returns None when the shape / dtype is not covered (the caller then uses the unfused route).
+    ``train``: -> (o, g, inv_q, inv_k, states) for linearmax_backward (states = the forward's workspace when it holds the
+    sequence split's prefix states, else None)."""
     L = _lib.lib()
     dev = q.device
     B, H, N, D = q.shape
@@ -220,18 +222,49 @@ def linearmax_forward_fused(q, k, v, return_stats=False):
     prob = _problem(q, k, q.dtype, q.dtype, 1, True, 1.0, 0.0)
     if B * H > 65535:
         return None
+    if train and not L.fastmax_hip_linearmax_train_supported(ctypes.byref(prob)):
+        return None
     # statistics + scan in one entry point (with the sequence split the statistics ride on the split's state pass)
     stats = torch.empty((2, B * H), dtype=torch.float32, device=dev)
     o = torch.empty((B, H, N, D), dtype=q.dtype, device=dev)
+    g = torch.empty((B, H, N), dtype=torch.float32, device=dev) if train else None
     wsb, wsp = _ws(L.fastmax_hip_linearmax_forward_auto_workspace(ctypes.byref(prob)), dev)
     with torch.cuda.device(dev):
         rc = L.fastmax_hip_linearmax_forward_auto(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
                                                   v.data_ptr(), _strides(v), stats[0].data_ptr(), stats[1].data_ptr(), o.data_ptr(),
-                                                  None, wsp, wsb.numel() if wsb is not None else 0, _stream(dev))
+                                                  g.data_ptr() if train else None, wsp, wsb.numel() if wsb is not None else 0,
+                                                  _stream(dev))
     if rc in (-2, -5):          # FASTMAX_E_BAD_SHAPE / _ALIGNMENT: not covered by the fused kernel
         return None
     _lib.check(rc, "fastmax_hip_linearmax_forward_auto")
+    if train:
+        nb = 0
+        if KEEP_STATES and wsb is not None:
+            nb = L.fastmax_hip_forward_state_bytes(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                                   v.data_ptr(), _strides(v), o.data_ptr())
+        return o, g, stats[0], stats[1], (wsb if 0 < nb <= wsb.numel() else None)
     return (o, stats[0], stats[1]) if return_stats else o
+
+
+def linearmax_backward(q, k, v, o, g, grad_o, inv_q, inv_k, states=None):
+    """backward of linearmax_forward_fused(train=True): q, k RAW, the scans apply the prologue while staging.
+    -> (dq_n, dk_n, dv): gradients wrt the NORMALISED q, k (finish with normalize_backward) and wrt v."""
+    L = _lib.lib()
+    dev = q.device
+    prob = _problem(q, k, q.dtype, o.dtype, 1, True, 1.0, 0.0)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=dev)
+    dk = torch.empty(q.shape, dtype=q.dtype, device=dev)
+    dv = torch.empty(v.shape, dtype=q.dtype, device=dev)
+    wsb, wsp = _ws(L.fastmax_hip_backward_workspace(ctypes.byref(prob)), dev)
+    with torch.cuda.device(dev):
+        rc = L.fastmax_hip_linearmax_backward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
+                                              v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr(), grad_o.data_ptr(),
+                                              _strides(grad_o), inv_q.data_ptr(), inv_k.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                              dv.data_ptr(), wsp, wsb.numel() if wsb is not None else 0,
+                                              None if states is None else states.data_ptr(),
+                                              0 if states is None else states.numel(), _stream(dev))
+    _lib.check(rc, "fastmax_hip_linearmax_backward")
+    return dq, dk, dv
 
 
 def effective_normalize_term(D, normalize_term, tensors_normalized):

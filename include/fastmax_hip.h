@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FASTMAX_ABI_VERSION 8   /* 8: the lmhead_ce_* and debug_gemm_stamps entry points are gone: the head's two products are plain library GEMMs by decision, see DESIGN.md, and the losing GEMM loop variants were removed; + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask, fastmax_hip_linearmax_forward_auto(_workspace); 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
+#define FASTMAX_ABI_VERSION 8   /* 8: the lmhead_ce_* and debug_gemm_stamps entry points are gone: the head's two products are plain library GEMMs by decision, see DESIGN.md, and the losing GEMM loop variants were removed; + fastmax_hip_tune_get, fastmax_hip_build_flags, fastmax_hip_normalize_stats2(_workspace), fastmax_hip_lora_{down,tn,up}_dropout, fastmax_hip_lora_dropout_mask, fastmax_hip_linearmax_forward_auto(_workspace), fastmax_hip_linearmax_backward, fastmax_hip_linearmax_train_supported; 7: + qlora_gemm_rope; 6: + qlora_gemm, nf4_dequantize_transposed, lmhead_ce_*; 5: + nf4 *_s entry points (double-quantised block scales); 4: + fastmax_hip_tune; 2: + normalize_cast/backward, rope_qkv_split(_backward), cross_entropy_forward/backward; 3: + lora_down/tn/up/scatter, normalize_*_expand, forward_state_bytes, backward_with_states */
 
 enum fastmax_dtype { FASTMAX_F32 = 0, FASTMAX_BF16 = 1, FASTMAX_F16 = 2 };
 
@@ -198,6 +198,26 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob,
                                        float* q_inv_norm, float* k_inv_norm,
                                        void* o, float* g,
                                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*      Training route of the same branch (masked, p = 1): the backward of fastmax_hip_linearmax_forward_auto.  q, k are the RAW
+ *      tensors and q_inv_norm / k_inv_norm what the forward left; the linear-time scans apply the prologue while staging (as the
+ *      forward does), so no normalised copy of q or k exists in memory.  dq, dk are the gradients wrt the NORMALISED q, k -- the
+ *      caller finishes with fastmax_hip_normalize_backward(q, dq, q_inv_norm) and (k, dk, k_inv_norm) (the autograd the reference
+ *      gets over fastmax_hack.py:38-43).  workspace = fastmax_hip_backward_workspace(prob); fwd_states = the forward's workspace
+ *      (prefix states of the sequence split) or NULL.  _train_supported: 1 where both directions are covered (else the caller
+ *      runs normalize_cast + fastmax_hip_forward / _backward).                                                              */
+int fastmax_hip_linearmax_train_supported(const fastmax_problem* prob);
+int fastmax_hip_linearmax_backward(const fastmax_problem* prob,
+                                   const void* q, const int64_t* q_strides,
+                                   const void* k, const int64_t* k_strides,
+                                   const void* v, const int64_t* v_strides,
+                                   const void* o, const float* g,
+                                   const void* grad_o, const int64_t* go_strides,
+                                   const float* q_inv_norm, const float* k_inv_norm,
+                                   void* dq, void* dk, void* dv,
+                                   void* workspace, size_t workspace_bytes,
+                                   const void* fwd_states, size_t fwd_state_bytes, void* stream);
+
 
 /* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:
  *      qkv (B, T, G, q_per_kv + 2, head_size), the QKV linear's output  ->  q (B, G*q_per_kv, T, head_size),

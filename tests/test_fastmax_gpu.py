@@ -709,6 +709,76 @@ print("narrow ok")
     assert r.returncode == 0 and "narrow ok" in r.stdout, r.stdout + r.stderr
 
 
+def _prologue_chain_fp64(x, gyn):
+    """gradient wrt x of y = (x - mean_D x) / max_n ||x_n - mean_D x_n|| given dL/dy (float64 autograd over fastmax_hack.py:38-43)"""
+    xr = torch.from_numpy(np.asarray(x, dtype=np.float64)).requires_grad_(True)
+    xc = xr - xr.mean(-1, keepdim=True)
+    y = xc / xc.norm(dim=-1).amax(-1)[..., None, None]
+    y.backward(torch.from_numpy(np.asarray(gyn, dtype=np.float64)))
+    return xr.grad.numpy()
+
+
+@pytest.mark.parametrize("dt,tf,tb", [(torch.float32, 2 * TOL_FWD, 4 * TOL_BWD), (torch.bfloat16, 1.6e-2, 3e-2), (torch.float16, 3e-3, 8e-3)])
+@pytest.mark.parametrize("shape", [(1, 2, 1024, 64), (2, 3, 700, 32), (1, 2, 2100, 128), (1, 40, 512, 64), (1, 2, 600, 48)])
+def test_linearmax_training_route_with_the_prologue_inside_the_scans(shape, dt, tf, tb):
+    """masked p=1 linearmax with gradients, N >= 512: ONE autograd node on the raw q, k, v (fastmax_hip_linearmax_forward_auto +
+    fastmax_hip_linearmax_backward: the scans normalise while staging, no normalised copy is stored) against the C oracle's scan
+    on float64-normalised inputs with the chain rule through the prologue, and against the two-node route (normalize_cast +
+    fastmax) it replaces.  D = 128 exists for bf16 only (other dtypes keep the two-node route there: also checked)."""
+    import importlib
+    fh = importlib.import_module("fastmax_experiments_amd.attention_mechanisms.fastmax_hack")      # the module, not the function
+    from oracle import c_oracle, fastmax_oracle as orc
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    q = (torch.randn(shape, generator=g) * 1.3 + 0.2).to(dt)
+    k = (torch.randn(shape, generator=g) * 0.7).to(dt)
+    v, go = (torch.randn(shape, generator=g).to(dt) for _ in range(2))
+    res = {}
+    for fused in (True, False):
+        fh.FUSED_TRAINING = fused
+        try:
+            qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+            o = fh.fastmax_hack(qq, kk, vv, p=1, mask=True)
+            o.backward(go.cuda())
+            res[fused] = [t.detach().float().cpu().numpy() for t in (o, qq.grad, kk.grad, vv.grad)]
+            assert o.dtype == dt and qq.grad.dtype == dt
+        finally:
+            fh.FUSED_TRAINING = True
+    qn, kn, vn, gn = (t.float().numpy() for t in (q, k, v, go))
+    qq64, kk64 = orc.normalize_qk(qn, kn)
+    ro, _ = c_oracle.fwd(qq64.astype(np.float32), kk64.astype(np.float32), vn, mask=True, nt=1.0, p=1)
+    dqn, dkn, dv = c_oracle.bwd(qq64.astype(np.float32), kk64.astype(np.float32), vn, gn, mask=True, nt=1.0, p=1)
+    want = [ro, _prologue_chain_fp64(qn, dqn), _prologue_chain_fp64(kn, dkn), dv]
+    for fused in (True, False):
+        for got, w, name, tol in zip(res[fused], want, ("o", "dq", "dk", "dv"), (tf, tb, tb, tb)):
+            assert rel_err(got, w) < tol, (fused, name)
+
+
+def test_grouped_linearmax_training_route_without_normalised_copies():
+    """grouped-query heads on the one-node route: q, v (B*G, rep, N, D) (v a stride-0 group view), K at its G heads -- same
+    output and gradients as the two-node grouped route"""
+    import importlib
+    fh = importlib.import_module("fastmax_experiments_amd.attention_mechanisms.fastmax_hack")      # the module, not the function
+    B, G, rep, N, D = 2, 2, 4, 640, 64
+    g = torch.Generator().manual_seed(11)
+    q0 = torch.randn(B * G, rep, N, D, generator=g).to(torch.bfloat16)
+    k0 = (torch.randn(B, G, N, D, generator=g) * 1.5).to(torch.bfloat16)
+    v0 = torch.randn(B, G, N, D, generator=g).to(torch.bfloat16)
+    go = torch.randn(B * G, rep, N, D, generator=g).to(torch.bfloat16).cuda()
+    res = {}
+    for fused in (True, False):
+        fh.FUSED_TRAINING = fused
+        try:
+            q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+            vv = v.view(B * G, 1, N, D).expand(B * G, rep, N, D)
+            o = fh.fastmax_hack_grouped(q, k, vv, rep, p=1)
+            o.backward(go)
+            res[fused] = [t.detach().float() for t in (o, q.grad, k.grad, v.grad)]
+        finally:
+            fh.FUSED_TRAINING = True
+    for a, b, name in zip(res[True], res[False], ("o", "dq", "dk", "dv")):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), name
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
 @pytest.mark.parametrize("shape", [(2, 3, 300, 64), (1, 2, 1000, 128), (1, 5, 17, 16), (1, 2, 260, 40), (2, 8, 513, 32), (1, 2, 300, 256),
                                    (1, 3, 130, 192)])

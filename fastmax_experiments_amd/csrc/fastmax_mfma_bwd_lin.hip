@@ -77,7 +77,7 @@ template <int DP, int SP, int TW> __device__ __forceinline__ void publish_state(
 // NW = 4: wave w owns query tile w and every output column.  NW = 8 (the variants whose LDS footprint allows one workgroup
 // per CU only): wave (wq = w & 3, hf = w >> 2) owns query tile wq and the column half hf of dQ and of the S2 state; the
 // 64 x 64 score-shaped tile is computed by both halves.
-template <int DP, typename TIN, int NW, bool NORM>
+template <int DP, typename TIN, int NW, bool NORM, bool BUF>
 __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
     const TIN* ob = reinterpret_cast<const TIN*>(prm.o) + (int64_t)bh * N * D;
     u32x4 rk[NPASS], rv[NPASS], rg[NPASS], ro[NPASS];
     float rw[NPASS];
-    const TileLoader<TIN, NPASS, RPP, true> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol),
+    const ScanLoader<BUF, TIN, NPASS, RPP> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol),
         gload(gb, prm.gos.sn, N, D, DP, srow, scol), oload(ob, D, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
         kload.load(n0 / C, rk);
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
             const int rc = row < N ? row : N - 1;
-            rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rc] : 0.f;
+            // the raw g_i: its reciprocal is taken where it is consumed -- taken here it would need the value at once, i.e.
+            // an s_waitcnt vmcnt(0) right behind the tile loads (the whole prefetch waited on at issue time)
+            rw[ps] = prm.g[(int64_t)bh * N + rc];
         }
     };
     for (int i = tid; i < (SP * SIMG) / 16; i += NT) *reinterpret_cast<f32x4*>(smem + S2I + 16 * i) = f32x4{0, 0, 0, 0};
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
                 part = rowgroup_sum<COLS>(part);                 // c_i = G_i . o_i
                 if (scol == COLS - 1) {
                     reinterpret_cast<float*>(smem + CS)[row] = part;
-                    reinterpret_cast<float*>(smem + WS)[row] = rw[ps];
+                    reinterpret_cast<float*>(smem + WS)[row] = n0 + row < N ? 1.0f / rw[ps] : 0.f;
                     if (n0 + row < N) prm.c[(int64_t)bh * N + n0 + row] = part;
                 }
             }
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 // NW = 8: wave (wk = w & 3, hf = w >> 2) owns the 16 keys of tile wk and the column half hf of dK, dV and of the R2 state
-template <int DP, typename TIN, int NW, bool NORM>
+template <int DP, typename TIN, int NW, bool NORM, bool BUF>
 __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
 
     u32x4 rq[NPASS], rk[NPASS], rv[NPASS], rg[NPASS];
     float rw[NPASS], rc[NPASS];
-    const TileLoader<TIN, NPASS, RPP, true> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
+    const ScanLoader<BUF, TIN, NPASS, RPP> qload(qb, prm.qs.sn, N, D, DP, srow, scol), kload(kb, prm.ks.sn, N, D, DP, srow, scol),
         vload(vb, prm.vs.sn, N, D, DP, srow, scol), gload(gb, prm.gos.sn, N, D, DP, srow, scol);
     auto issue = [&](int n0) {
         qload.load(n0 / C, rq);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = n0 + srow + ps * RPP;
             const int rcl = row < N ? row : N - 1;
-            rw[ps] = row < N ? 1.0f / prm.g[(int64_t)bh * N + rcl] : 0.f;
+            rw[ps] = prm.g[(int64_t)bh * N + rcl];                   // raw g_i, see the dQ kernel
             rc[ps] = prm.c[(int64_t)bh * N + rcl];
         }
     };
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
                 float xq[EPL], xg[EPL];
                 piece_to_float<TIN>(rq[ps], xq);
                 piece_to_float<TIN>(rg[ps], xg);
-                const float wi = rw[ps], ei = -wi * rc[ps];
+                const float wi = n0 + row < N ? 1.0f / rw[ps] : 0.f, ei = -wi * rc[ps];
                 if constexpr (NORM) {
                     float xk[EPL];
                     piece_to_float<TIN>(rk[ps], xk);
@@ -424,10 +426,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                kf[ks].p[p] = ld_row8<DP>(smem, KI + p * IMG, kj, 4 * ks + q4);
-                vf[ks].p[p] = ld_row8<DP>(smem, VI + p * IMG, kj, 4 * ks + q4);
-            }
+            for (int p = 0; p < NP; ++p) vf[ks].p[p] = ld_row8<DP>(smem, VI + p * IMG, kj, 4 * ks + q4);
         f32x4 dkacc[MT], dvacc[DT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -450,6 +449,13 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
                 dvacc[t] = mfma_parts<SP, NP>(rtf, kpf, dvacc[t]);
             }
         }
+        // the K row fragments are first needed by the score tiles: read here, not above (at D = 128 the state products hold
+        // the whole register file; 16 more live registers there spilled into the chunk loop)
+        if constexpr (DP == 128) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) kf[ks].p[p] = ld_row8<DP>(smem, KI + p * IMG, kj, 4 * ks + q4);
         Frag<2> tf[2], pf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -541,8 +547,8 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
     }
 }
 
-template <int DP, typename TIN, bool NORM>
-static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
+template <int DP, typename TIN, bool NORM, bool BUF>
+static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
     // (one workgroup per CU, column halves per wave) everywhere else
@@ -553,8 +559,8 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256;
     static_assert(lds_kv <= 160 * 1024 && lds_q <= 160 * 1024, "LDS budget");
     static_assert(NWKV == 4 || 8 * 2 * 16 * (DP / 2) * 4 <= 4 * NP * IMG, "dK/dV staging areas fit the freed images");
-    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM>;
-    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM>;
+    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM, BUF>;
+    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM, BUF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
@@ -571,6 +577,15 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     }
     hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
     return (int)hipGetLastError();
+}
+
+template <int DP, typename TIN, bool NORM>
+static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
+    // buffer-descriptor tile loads when every (b,h) slab spans less than their 31-bit offsets (all but pathological strides)
+    const int es = (int)sizeof(TIN);
+    const bool buf = quad32_span_ok(prm.qs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.ks.sn, prm.N, prm.D, es) &&
+                     quad32_span_ok(prm.vs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.gos.sn, prm.N, prm.D, es);
+    return buf ? launch_lin_bwd_b<DP, TIN, NORM, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false>(prm, BH, stream, prob);
 }
 
 bool lin_bwd_supported(const fastmax_problem& p);

@@ -407,6 +407,40 @@ struct BufTileLoader {
         for (int ps = 0; ps < NPASS; ++ps) r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ps] + t, 0, AUX);
     }
 };
+// the scan kernels' streamed-once tile loader: buffer descriptors where every slab fits their 31-bit offsets (BUF, decided on the
+// host), else 64-bit pointer arithmetic
+template <bool BUF, typename TIN, int NPASS, int RPP> struct ScanLoader;
+// The buffer form for kernels that stream four or five tensors with every register taken (the linear-time backward at D = 128):
+// nothing per (loader, pass) lives in a vector register across the chunk loop -- the offset of a piece is re-formed from the
+// thread's row / column (shared by all loaders) with one 24-bit multiply-add and one add per load; the row stride, the tile
+// stride and the descriptor are scalars.  BufTileLoader keeps NPASS offsets per loader: at four loaders the D = 128 dK/dV
+// kernel spilled them, and a scratch reload in front of the prefetch loads is a full memory round trip per chunk.
+template <typename TIN, int NPASS, int RPP> struct ScanLoader<true, TIN, NPASS, RPP> {
+    __amdgpu_buffer_rsrc_t rs;
+    int row_bytes, base_off, srow;
+    __device__ __forceinline__ ScanLoader(const TIN* base, int64_t sn, int nrows, int D, int, int srow_, int scol) : srow(srow_) {
+        constexpr int EPL = InTraits<TIN>::EPL;
+        row_bytes = __builtin_amdgcn_readfirstlane((int)sn * (int)sizeof(TIN));
+        const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(base), 0, nrec, 0x00020000);
+        base_off = scol * EPL < D ? scol * 16 : (int)0x80000000;       // a padded head column is always out of range
+    }
+    __device__ __forceinline__ void load(int tile, u32x4 (&r)[NPASS]) const {
+        const int t = tile * 64 * row_bytes;
+        // opaque copy of the row index: without it the compiler hoists the (loop-invariant) products out of the chunk loop,
+        // runs out of registers, spills them and reloads each one with s_waitcnt vmcnt(0) between the prefetch loads
+        int sr = srow;
+        asm volatile("" : "+v"(sr));
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+            r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)__umul24((unsigned)(sr + ps * RPP), (unsigned)row_bytes) + base_off + t, 0, 2);
+    }
+};
+template <typename TIN, int NPASS, int RPP> struct ScanLoader<false, TIN, NPASS, RPP> : TileLoader<TIN, NPASS, RPP, true> {
+    __device__ __forceinline__ ScanLoader(const TIN* b, int64_t sn, int nrows, int D, int DP, int srow, int scol)
+        : TileLoader<TIN, NPASS, RPP, true>(b, sn, nrows, D, DP, srow, scol) {}
+};
+
 // host side: the byte range of one (b,h) slab fits the 31-bit offsets above
 inline bool quad32_span_ok(int64_t sn, int nrows, int D, int elem_bytes) {
     return sn >= 0 && ((int64_t)(nrows > 0 ? nrows - 1 : 0) * sn + D) * elem_bytes < (int64_t)0x40000000;

@@ -88,9 +88,18 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
 
     u32x4 rk[NPASS], rv[NPASS];
     const TileLoader<TIN, NPASS, RPP> kload(kb, kst.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    float rgg[NPASS], rcc[NPASS];                                  // RS: g_i, c_i of the rows in flight (raw: see bwd_p1_dq_kernel)
     auto issue = [&](int n0) {
         kload.load(n0 / C, rk);
         vload.load(n0 / C, rv);
+        if constexpr (RS) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int gi = n0 + srow + ps * RPP, gc = gi < N ? gi : N - 1;
+                rgg[ps] = prm.g[(int64_t)bh * N + gc];
+                rcc[ps] = prm.c[(int64_t)bh * N + gc];
+            }
+        }
     };
     float best = 0.f;
     f32x4 s2acc[NSL][MT];
@@ -139,9 +148,9 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
             piece_to_float<TIN>(rk[ps], xk);
             piece_to_float<TIN>(rv[ps], xv);
             if constexpr (RS) {
-                const int gi = n0 + row, gc = gi < N ? gi : N - 1;
-                const float wi = gi < N ? 1.0f / prm.g[(int64_t)bh * N + gc] : 0.f;
-                const float ei = -wi * prm.c[(int64_t)bh * N + gc];
+                const int gi = n0 + row;
+                const float wi = gi < N ? 1.0f / rgg[ps] : 0.f;
+                const float ei = -wi * rcc[ps];
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) xv[e] *= wi;
                 if constexpr (NORM == 1) {                               // linearmax training route: q arrives raw

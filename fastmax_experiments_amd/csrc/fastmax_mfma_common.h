@@ -441,6 +441,33 @@ template <typename TIN, int NPASS, int RPP> struct ScanLoader<false, TIN, NPASS,
         : TileLoader<TIN, NPASS, RPP, true>(b, sn, nrows, D, DP, srow, scol) {}
 };
 
+// 16-byte pieces of single rows (a wave's query rows straight into B fragments): same two forms.  The pointer form costs a
+// 64-bit address per piece; eight of them, hoisted out of the chunk loop and spilled, serialised the fp32 D = 128 forward's
+// Q loads (scratch reload + s_waitcnt before every load).
+template <bool BUF, typename TIN> struct RowPieceLoader;
+template <typename TIN> struct RowPieceLoader<true, TIN> {
+    __amdgpu_buffer_rsrc_t rs;
+    int row_bytes, D;
+    __device__ __forceinline__ RowPieceLoader(const TIN* base, int64_t sn, int nrows, int D_) : D(D_) {
+        row_bytes = __builtin_amdgcn_readfirstlane((int)sn * (int)sizeof(TIN));
+        const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(base), 0, nrec, 0x00020000);
+    }
+    // rows past the tensor and pieces past D read as zeros (range check of the descriptor)
+    __device__ __forceinline__ u32x4 load(int row, int piece) const {
+        constexpr int EPL = InTraits<TIN>::EPL;
+        const int off = piece * EPL < D ? (int)__umul24((unsigned)row, (unsigned)row_bytes) + piece * 16 : (int)0x80000000;
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2);
+    }
+};
+template <typename TIN> struct RowPieceLoader<false, TIN> {
+    const TIN* base;
+    int64_t sn;
+    int nrows, D;
+    __device__ __forceinline__ RowPieceLoader(const TIN* b, int64_t sn_, int nrows_, int D_) : base(b), sn(sn_), nrows(nrows_), D(D_) {}
+    __device__ __forceinline__ u32x4 load(int row, int piece) const { return load_piece<TIN, true>(base, sn, row, nrows, piece, D); }
+};
+
 // host side: the byte range of one (b,h) slab fits the 31-bit offsets above
 inline bool quad32_span_ok(int64_t sn, int nrows, int D, int elem_bytes) {
     return sn >= 0 && ((int64_t)(nrows > 0 ? nrows - 1 : 0) * sn + D) * elem_bytes < (int64_t)0x40000000;

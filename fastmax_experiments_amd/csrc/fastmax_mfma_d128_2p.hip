@@ -23,7 +23,7 @@ struct D128Params {
     int nseg, cps;
 };
 
-template <typename TIN, bool NORM>
+template <typename TIN, bool NORM, bool BUF>
 __global__ __launch_bounds__(512, 1) void fwd_p1_mfma_d128_2p_kernel(D128Params prm) {
     constexpr int NP = 2, EPL = InTraits<TIN>::EPL;
     static_assert(InTraits<TIN>::NP == 2, "two-part operands");
@@ -50,15 +50,18 @@ __global__ __launch_bounds__(512, 1) void fwd_p1_mfma_d128_2p_kernel(D128Params 
     const bool colok = scol * EPL < D;
 
     u32x4 rk[NPASS], rv[NPASS], rq[KS][QL];
-    const TileLoader<TIN, NPASS, RPP, true> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    const ScanLoader<BUF, TIN, NPASS, RPP> kload(kb, prm.ks.sn, N, D, DP, srow, scol), vload(vb, prm.vs.sn, N, D, DP, srow, scol);
+    const RowPieceLoader<BUF, TIN> qrows(qb, prm.qs.sn, N, D);
     auto issue = [&](int c) {
         kload.load(c, rk);
         vload.load(c, rv);
         const int row = c * C + 16 * qt + r;                       // this wave's query row on this lane
+        int q4o = q4;                                              // opaque: the eight piece offsets are re-formed per chunk, not hoisted and spilled
+        asm volatile("" : "+v"(q4o));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int u = 0; u < QL; ++u) rq[ks][u] = load_piece<TIN, true>(qb, prm.qs.sn, row, N, (32 * ks + 8 * q4) / EPL + u, D);
+            for (int u = 0; u < QL; ++u) rq[ks][u] = qrows.load(row, (32 * ks + 8 * q4o) / EPL + u);
     };
     bf16x8 ones;
 #pragma unroll
@@ -276,12 +279,12 @@ __global__ __launch_bounds__(512, 1) void fwd_p1_mfma_d128_2p_kernel(D128Params 
     }
 }
 
-template <typename TIN, bool NORM>
-static int launch_d128_2p_t(const D128Params& prm, int nb, hipStream_t stream) {
+template <typename TIN, bool NORM, bool BUF>
+static int launch_d128_2p_b(const D128Params& prm, int nb, hipStream_t stream) {
     constexpr int DP = 128;
     constexpr int lds = 4 * 64 * DP * 2 + 2 * (DP + 16) * DP * 2 + DP * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fwd_p1_mfma_d128_2p_kernel<TIN, NORM>;
+    auto kern = fwd_p1_mfma_d128_2p_kernel<TIN, NORM, BUF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -290,6 +293,14 @@ static int launch_d128_2p_t(const D128Params& prm, int nb, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, stream, prm);
     return (int)hipGetLastError();
+}
+
+template <typename TIN, bool NORM>
+static int launch_d128_2p_t(const D128Params& prm, int nb, hipStream_t stream) {
+    // K / V tiles through buffer descriptors when a (b,h) slab fits their 31-bit offsets
+    const bool buf = quad32_span_ok(prm.ks.sn, prm.N, prm.D, (int)sizeof(TIN)) && quad32_span_ok(prm.vs.sn, prm.N, prm.D, (int)sizeof(TIN)) &&
+                     quad32_span_ok(prm.qs.sn, prm.N, prm.D, (int)sizeof(TIN));
+    return buf ? launch_d128_2p_b<TIN, NORM, true>(prm, nb, stream) : launch_d128_2p_b<TIN, NORM, false>(prm, nb, stream);
 }
 
 bool mfma_d128_2p_supported(const fastmax_problem& p) {

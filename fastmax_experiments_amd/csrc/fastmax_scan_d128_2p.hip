@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void scan_prep_kernel(const void* go, Strides3
     }
 }
 
-template <typename TIN, int MODE, bool STATE_ONLY = false>
+template <typename TIN, int MODE, bool STATE_ONLY, bool BUF>
 __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
     constexpr int NP = 2, EPL = InTraits<TIN>::EPL;
     static_assert(InTraits<TIN>::NP == 2, "two-part operands");
@@ -91,16 +91,19 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
     float rws[NPASS];               // w of the staged rows (y or z scaled by it)
     float rwx = 0.f, rex = 0.f;     // w, e of this lane's output row
     float rec = 0.f;                // e of row tid of the chunk (threads 0..63), for EV
-    const TileLoader<TIN, NPASS, RPP, true> yload(yb, prm.ys.sn, N, D, DP, srow, scol), zload(zb, prm.zs.sn, N, D, DP, srow, scol);
+    const ScanLoader<BUF, TIN, NPASS, RPP> yload(yb, prm.ys.sn, N, D, DP, srow, scol), zload(zb, prm.zs.sn, N, D, DP, srow, scol);
+    const RowPieceLoader<BUF, TIN> xrows(xb, prm.xs.sn, N, D);
     auto issue = [&](int c) {
         yload.load(c, ry);
         zload.load(c, rz);
         const int row = c * C + 16 * qt + r;                       // this wave's output row on this lane
         if constexpr (!STATE_ONLY) {
+            int q4o = q4;                                          // opaque: piece offsets re-formed per chunk (see fastmax_mfma_d128_2p.hip)
+            asm volatile("" : "+v"(q4o));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int u = 0; u < QL; ++u) rx[ks][u] = load_piece<TIN, true>(xb, prm.xs.sn, row, N, (32 * ks + 8 * q4) / EPL + u, D);
+                for (int u = 0; u < QL; ++u) rx[ks][u] = xrows.load(row, (32 * ks + 8 * q4o) / EPL + u);
         }
         if constexpr (YSCALE || ZSCALE) {
 #pragma unroll
@@ -193,6 +196,8 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
         Frag<NP> xf[KS];
         const float alpha_r = MODE == SCAN_DQ ? rex : 1.0f;          // alpha of this lane's output row (DQ), else unused / 1
         if constexpr (!STATE_ONLY) {
+            int q4o = q4;                                          // opaque: piece offsets re-formed per chunk (see fastmax_mfma_d128_2p.hip)
+            asm volatile("" : "+v"(q4o));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float xq[8];
@@ -332,12 +337,12 @@ __global__ __launch_bounds__(512, 1) void scan_d128_2p_kernel(ScanParams prm) {
     }
 }
 
-template <typename TIN, int MODE, bool STATE_ONLY>
-static int launch_scan_k(const ScanParams& prm, int nb, hipStream_t stream) {
+template <typename TIN, int MODE, bool STATE_ONLY, bool BUF>
+static int launch_scan_kb(const ScanParams& prm, int nb, hipStream_t stream) {
     constexpr int DP = 128;
     constexpr int lds = 4 * 64 * DP * 2 + 2 * DP * DP * 2 + DP * 4 + 256;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_d128_2p_kernel<TIN, MODE, STATE_ONLY>;
+    auto kern = scan_d128_2p_kernel<TIN, MODE, STATE_ONLY, BUF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -346,6 +351,14 @@ static int launch_scan_k(const ScanParams& prm, int nb, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, stream, prm);
     return (int)hipGetLastError();
+}
+
+template <typename TIN, int MODE, bool STATE_ONLY>
+static int launch_scan_k(const ScanParams& prm, int nb, hipStream_t stream) {
+    // streamed y / z tiles through buffer descriptors when a (b,h) slab fits their 31-bit offsets
+    const bool buf = quad32_span_ok(prm.ys.sn, prm.N, prm.D, (int)sizeof(TIN)) && quad32_span_ok(prm.zs.sn, prm.N, prm.D, (int)sizeof(TIN)) &&
+                     quad32_span_ok(prm.xs.sn, prm.N, prm.D, (int)sizeof(TIN));
+    return buf ? launch_scan_kb<TIN, MODE, STATE_ONLY, true>(prm, nb, stream) : launch_scan_kb<TIN, MODE, STATE_ONLY, false>(prm, nb, stream);
 }
 
 // one scan: with a sequence split, the segments' own sums first

@@ -20,6 +20,9 @@ CASES = [
     ("headline bf16 p=1", "fastmax", (16, 32, 4096, 64), "bf16"),
     ("headline f32 p=1", "fastmax", (16, 32, 4096, 64), "f32"),
     ("D=128 many heads bf16", "fastmax", (16, 32, 4096, 128), "bf16"),
+    ("C4 heads f32 p=1", "fastmax", (2, 32, 4096, 128), "f32"),
+    ("C5 heads f32 p=1 16k", "fastmax", (1, 32, 16384, 128), "f32"),
+    ("C5 heads f32 linearmax 16k", "linearmax", (1, 32, 16384, 128), "f32"),
 ]
 
 

@@ -350,8 +350,8 @@ int fastmax_hip_linearmax_forward(const fastmax_problem* prob, const void* q, co
 // launch); otherwise they are the paired statistics pass.  q_inv_norm / k_inv_norm (B*H floats each) are OUTPUTS here.
 // workspace = [forward workspace | statistic words].
 static size_t linearmax_stats_bytes(int B, int H, int N) {
-    const size_t per_head = (size_t)((N + 255) / 256) + 32;          // statistics-only blocks of 256 rows + one word per segment
-    return sizeof(unsigned int) * 2 * (size_t)B * H * per_head;
+    const size_t per_head = (size_t)((N + 255) / 256) + 32;          // statistics-only blocks of 256 rows + one key per segment
+    return sizeof(unsigned long long) * 2 * (size_t)B * H * per_head;
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -362,8 +362,8 @@ size_t fastmax_hip_linearmax_forward_auto_workspace(const fastmax_problem* prob)
 
 int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                        const int64_t* k_strides, const void* v, const int64_t* v_strides, float* q_inv_norm,
-                                       float* k_inv_norm, void* o, float* g, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       float* k_inv_norm, int* q_nstar, int* k_nstar, void* o, float* g, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     int rc = validate(prob);
     if (rc) return rc;
     if (!q || !k || !v || !o || !q_strides || !k_strides || !v_strides || !q_inv_norm || !k_inv_norm) return FASTMAX_E_NULL;
@@ -374,7 +374,8 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob, const void* 
         return FASTMAX_E_ALIGNMENT;
     const size_t fwd_bytes = align256(fastmax_hip_forward_workspace(prob));
     if (!workspace || workspace_bytes < fwd_bytes + linearmax_stats_bytes(prob->B, prob->H, prob->Nq)) return FASTMAX_E_WORKSPACE;
-    const LinearmaxStats stats{q_inv_norm, k_inv_norm, reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + fwd_bytes)};
+    const LinearmaxStats stats{q_inv_norm, k_inv_norm, reinterpret_cast<unsigned int*>(static_cast<char*>(workspace) + fwd_bytes),
+                               q_nstar, k_nstar};
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, fwd_bytes,
               reinterpret_cast<hipStream_t>(stream), &stats};
     if (mfma_d128_2p_supported(*prob)) return launch_fwd_mfma_d128_2p(a, q_inv_norm, k_inv_norm);
@@ -384,7 +385,8 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob, const void* 
 // Training route of the same branch: the backward of fastmax_hip_linearmax_forward_auto.  q, k are the RAW tensors and
 // q_inv_norm / k_inv_norm what the forward left; the linear-time scans apply the prologue while staging (as the forward does), so
 // no normalised copy of q or k is ever stored.  dq, dk are the gradients wrt the NORMALISED q, k: the caller finishes with
-// fastmax_hip_normalize_backward(q, dq, q_inv_norm) / (k, dk, k_inv_norm).  fwd_states = the forward's workspace (its prefix
+// fastmax_hip_normalize_backward(q, dq, q_inv_norm) / (k, dk, k_inv_norm) -- unless flags bit 0 is set: then the dK/dV kernel
+// applies the prologue's backward to its dK tile itself and dk is the gradient wrt the raw k (one k head per query head only).  fwd_states = the forward's workspace (its prefix
 // states), or null.  FASTMAX_E_BAD_SHAPE where the linear-time backward does not cover the problem (fastmax_hip_linearmax_train_supported).
 int fastmax_hip_linearmax_train_supported(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
@@ -395,8 +397,8 @@ int fastmax_hip_linearmax_train_supported(const fastmax_problem* prob) {
 int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                    const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o, const float* g,
                                    const void* grad_o, const int64_t* go_strides, const float* q_inv_norm, const float* k_inv_norm,
-                                   void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, const void* fwd_states,
-                                   size_t fwd_state_bytes, void* stream) {
+                                   const int* k_nstar, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                                   const void* fwd_states, size_t fwd_state_bytes, int flags, void* stream) {
     int rc = validate(prob);
     if (rc) return rc;
     if (!q || !k || !v || !o || !g || !grad_o || !dq || !dk || !dv || !q_strides || !k_strides || !v_strides || !go_strides ||
@@ -411,6 +413,8 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, c
               workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
     a.qscale = q_inv_norm;
     a.kscale = k_inv_norm;
+    a.fuse_prologue = (flags & 1) && k_nstar;
+    a.k_nstar = k_nstar;
     const SplitPlan plan = split_plan(*prob);
     if (fwd_states && plan.nseg > 1 && fwd_state_bytes >= split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128) &&
         !(reinterpret_cast<uintptr_t>(fwd_states) & 15))

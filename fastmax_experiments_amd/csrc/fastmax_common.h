@@ -79,7 +79,8 @@ namespace fastmax {
 // inv_k (B*H floats each) before its main kernel reads them; partials = scratch words (linearmax_stats_words(B, H, N))
 struct LinearmaxStats {
     float *inv_q, *inv_k;
-    unsigned int* partials;
+    unsigned int* partials;              // scratch: 32-bit words (paired statistics pass) or 64-bit (value, ~row) keys (state pass)
+    int *nstar_q = nullptr, *nstar_k = nullptr;   // optional: the row that attains the max-norm, per head (-1: not determined)
 };
 struct FwdArgs {
     fastmax_problem prob;
@@ -105,6 +106,8 @@ struct BwdArgs {
     // linearmax training route (fastmax_hip_linearmax_backward): q, k are the RAW tensors; the scan kernels apply the prologue
     // (x - mean) * scale[bh] while staging, as the fused forward does, and return the gradients wrt the normalised q, k
     const float *qscale = nullptr, *kscale = nullptr;
+    int fuse_prologue = 0;               // bit 0: dk leaves as the gradient wrt the raw k (prologue backward inside the dK/dV kernel)
+    const int* k_nstar = nullptr;        //        the row of k that attains the max-norm, per head (from the forward)
 };
 
 int launch_fwd_quadratic(const FwdArgs& a);
@@ -143,6 +146,8 @@ SplitPlan split_plan(const fastmax_problem& p);
 size_t split_workspace_bytes(const fastmax_problem& p, int dp);
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
 int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp);
+int launch_normalize_fixadd(const void* x, Strides3 xs, int dtype, const float* inv_norm, const float* part_dot,
+                            const int* nstar, int nblk, int B, int H, int N, int D, void* gx, hipStream_t stream);
 int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);
 bool mfma_d128_2p_supported(const fastmax_problem& p);
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,

@@ -28,6 +28,11 @@ struct LinBwdParams {
     int nseg, cps;
     // NORM (linearmax training route): q, k are raw; the prologue (x - mean) * scale[bh] is applied while staging
     const float *qscale, *kscale;
+    // FUSEK (with NORM): dk leaves as the gradient wrt the RAW k -- the prologue's row-wise backward inv (g - mean_D g) is applied
+    // to the dK tile before it is stored, and every block leaves sum_n g_n . xc_n for the one-row fix-up (fastmax_normalize.hip),
+    // [bh][nseg] entries
+    float* kpart_dot;
+    const int* k_nstar;             // the row of k that attains the max-norm, per head (found by the forward's statistics)
 };
 
 // Stage a wave's 16 x W fp32 accumulator tile (lane = row r, acc[t][reg] = column 16t + 4q4 + reg) through a wave-private
@@ -56,6 +61,9 @@ __device__ __forceinline__ void store_cols16(char* ost, const f32x4 (&acc)[W / 1
 template <int DP, int SP, int TW> __device__ __forceinline__ void publish_state(char* smem, int base, int simg, const f32x4 (&acc)[TW],
                                                                   float scale, int row, int q4, int t0) {
     // accumulators (rows = 16(t0+t) + 4q4 + reg, column = `row` on the lane) -> bf16 image row `row`
+    // (`row` is made opaque: the TW store addresses are loop invariants the compiler otherwise hoists out of the chunk loop and,
+    // in the kernels that use every register, spills -- each reload then sits behind an s_waitcnt vmcnt(0))
+    asm volatile("" : "+v"(row));
 #pragma unroll
     for (int tt = 0; tt < TW; ++tt) {
         const int t = t0 + tt;
@@ -289,8 +297,9 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 // NW = 8: wave (wk = w & 3, hf = w >> 2) owns the 16 keys of tile wk and the column half hf of dK, dV and of the R2 state
-template <int DP, typename TIN, int NW, bool NORM, bool BUF>
+template <int DP, typename TIN, int NW, bool NORM, bool BUF, bool FUSEK = false>
 __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
+    static_assert(!FUSEK || NORM, "the fused prologue backward belongs to the linearmax route");
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int QI = 0, KI = NP * IMG, VI = 2 * NP * IMG, GI = 3 * NP * IMG, R2I = 4 * NP * IMG;
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
     constexpr int NT = 64 * NW, HF = NW / 4;
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = C / RPP;
     constexpr int PARTG = RQ + 2 * DP * 4, PARTQ = PARTG + RPP * DP * 4, ES = PARTQ + RPP * DP * 4;
+    constexpr int RSUM = ES + 256;                                           // FUSEK: NW x 16 row sums of the dK tile (+ the final reduce)
     constexpr int KS = DP / 32, NSL = DP / 64;
     constexpr int MT = (DP / 16) / HF, DT = (DP / 16) / HF;                  // column tiles of this wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) r2acc[sl][dt] = f32x4{0, 0, 0, 0};
 
+    float kdot = 0.f;                                            // FUSEK: this thread's share of sum_n dk'_n . y_n
     const int nchunks = (N + C - 1) / C;
     const int c_begin = seg * prm.cps, c_end = min(nchunks, c_begin + prm.cps);
     if (seg + 1 < prm.nseg) {
@@ -525,7 +536,41 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
                 for (int sl = 0; sl < NSL; ++sl) r2acc[sl][dt] = mfma_parts<NP, NP>(gtf, qf[sl], r2acc[sl][dt]);
             }
         }
+        float krs = 0.f;
+        if constexpr (FUSEK) {
+            // prologue backward on the dK tile: row sums (for the mean over D) and the dot with the normalised key rows (still in
+            // the K image until B2); lane (r, q4) holds columns 16 (t0 + t) + 4 q4 + i of key row kj
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int c0 = 16 * (t0 + t) + 4 * q4;
+                f32x4 y = {0, 0, 0, 0};
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bf16x4 yb = *reinterpret_cast<const bf16x4*>(smem + KI + p * IMG + img_off<DP>(kj, c0 >> 3) + ((c0 & 7) << 1));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += (float)yb[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    krs += dkacc[t][i];
+                    kdot = fmaf(dkacc[t][i], y[i], kdot);
+                }
+            }
+            krs += __shfl_xor(krs, 16, 64);
+            krs += __shfl_xor(krs, 32, 64);
+            if constexpr (NW == 8) {
+                if (q4 == 0) reinterpret_cast<float*>(smem + RSUM)[16 * w + r] = krs;
+            }
+        }
         __syncthreads();                                             // B2
+        if constexpr (FUSEK) {
+            if constexpr (NW == 8) krs += reinterpret_cast<const float*>(smem + RSUM)[16 * (w ^ 4) + r];     // the other column half
+            const float kmean = krs * invD, kinv = prm.kscale[bh];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dkacc[t][i] = (dkacc[t][i] - kmean) * kinv;      // padded columns are not stored
+        }
         if constexpr (NW == 4) {
             store_tile16<DP>(smem + w * (16 * DP * 4), dkacc, 1.0f, lane, prm.dk, prm.grad_dtype,   // a is already folded in
                              ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
@@ -545,9 +590,21 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
         }
         __syncthreads();
     }
+    if constexpr (FUSEK) {
+        // one record per block: sum_n dk'_n . xc_n (xc = y / inv), for the one-row fix-up
+        kdot = wave_sum(kdot);
+        float* fd = reinterpret_cast<float*>(smem + RSUM);
+        if (lane == 0) fd[w] = kdot;
+        __syncthreads();
+        if (tid == 0) {
+            float sd = 0.f;
+            for (int i = 0; i < NW; ++i) sd += fd[i];
+            prm.kpart_dot[(int64_t)bh * prm.nseg + seg] = sd / prm.kscale[bh];
+        }
+    }
 }
 
-template <int DP, typename TIN, bool NORM, bool BUF>
+template <int DP, typename TIN, bool NORM, bool BUF, bool FUSEK>
 static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
@@ -556,11 +613,11 @@ static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream,
     constexpr int RPPQ = 64 * NWQ / (DP / EPL), RPPKV = 64 * NWKV / (DP / EPL);
     constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
     constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPPQ * DP * 4 + 512 + (NWQ == 8 ? 8 * 16 * (DP / 2) * 4 : 0);
-    constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256;
+    constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256 + 640;
     static_assert(lds_kv <= 160 * 1024 && lds_q <= 160 * 1024, "LDS budget");
     static_assert(NWKV == 4 || 8 * 2 * 16 * (DP / 2) * 4 <= 4 * NP * IMG, "dK/dV staging areas fit the freed images");
     auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM, BUF>;
-    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM, BUF>;
+    auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM, BUF, FUSEK>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
@@ -576,6 +633,9 @@ static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
+    if constexpr (FUSEK)
+        return launch_normalize_fixadd(prm.k, prm.ks, prob.in_dtype, prm.kscale, prm.kpart_dot, prm.k_nstar, prm.nseg, prob.B, prob.H,
+                                       prm.N, prm.D, prm.dk, stream);
     return (int)hipGetLastError();
 }
 
@@ -585,15 +645,20 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     const int es = (int)sizeof(TIN);
     const bool buf = quad32_span_ok(prm.qs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.ks.sn, prm.N, prm.D, es) &&
                      quad32_span_ok(prm.vs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.gos.sn, prm.N, prm.D, es);
-    return buf ? launch_lin_bwd_b<DP, TIN, NORM, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false>(prm, BH, stream, prob);
+    if constexpr (NORM) {
+        if (prm.kpart_dot) return buf ? launch_lin_bwd_b<DP, TIN, true, true, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, true>(prm, BH, stream, prob);
+    }
+    return buf ? launch_lin_bwd_b<DP, TIN, NORM, true, false>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false, false>(prm, BH, stream, prob);
 }
 
 bool lin_bwd_supported(const fastmax_problem& p);
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-// workspace = [ c (B,H,N) | forward-scan states | reverse-scan states ]   (the states only when the sequence is split)
+// per (head, segment) records of the fused prologue backward: one float (32 segments at most)
+static size_t lin_bwd_fuse_bytes(const fastmax_problem& p) { return align16((size_t)p.B * p.H * 32 * 4); }
+// workspace = [ c (B,H,N) | forward-scan states | reverse-scan states | fused-prologue records ]   (the states only when the sequence is split)
 size_t lin_bwd_workspace(const fastmax_problem& p) {
     size_t bytes = align16(sizeof(float) * (size_t)p.B * p.H * p.Nq);
-    if (lin_bwd_supported(p)) bytes += 2 * align16(split_workspace_bytes(p, p.D <= 64 ? 64 : 128));
+    if (lin_bwd_supported(p)) bytes += 2 * align16(split_workspace_bytes(p, p.D <= 64 ? 64 : 128)) + lin_bwd_fuse_bytes(p);
     return bytes;
 }
 
@@ -618,7 +683,11 @@ int launch_bwd_lin(const BwdArgs& a) {
     float* rstate = reinterpret_cast<float*>(ws + coff + sbytes);
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                      cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
-                     fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale};
+                     fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale, nullptr, nullptr};
+    if ((a.fuse_prologue & 1) && a.qscale && a.kscale && a.k_nstar) {
+        prm.kpart_dot = reinterpret_cast<float*>(ws + coff + 2 * sbytes);
+        prm.k_nstar = a.k_nstar;
+    }
     const int BH = a.prob.B * a.prob.H;
     if (plan.nseg > 1 && !a.fwd_states) {
         // forward-scan states (sum k v^T, sum k) exactly as the forward's; the reverse-scan states need c_i, which the dQ

@@ -24,7 +24,7 @@ struct StateParams {
     // the prefix pass applies the scale), every block leaves max ||row - mean||^2 of its rows in partials[which][bh][seg]
     const void* q;
     Strides3 qs;
-    unsigned int* partials;   // [2 (q, k)][B*H][pw]
+    unsigned long long* partials;   // [2 (q, k)][B*H][pw] keys: (bits of max ||row - mean||^2) << 32 | ~row
     int BH, pw;
 };
 constexpr int STAT_LT = 4;    // chunks (of 64 rows) per statistics-only block
@@ -101,7 +101,11 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
             }
         }
     };
-    float best = 0.f;
+    unsigned long long best = 0ull;                                // (squared norm bits, ~row): max = largest norm, lowest row on ties
+    auto keep_best = [&](float nn, int row) __attribute__((always_inline)) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(nn) << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);
+        best = key > best ? key : best;
+    };
     f32x4 s2acc[NSL][MT];
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl)
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { ck[e] = 0.f; cv[e] = 0.f; }
 
-    auto rowstat = [&](const u32x4& piece) __attribute__((always_inline)) {
+    auto rowstat = [&](const u32x4& piece, int row) __attribute__((always_inline)) {
         float xk[EPL];
         piece_to_float<TIN>(piece, xk);
         float sk = 0.f;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
             const float xc = fmaf(xk[e], ksc_c, nmk);
             nn = fmaf(xc, xc, nn);
         }
-        best = fmaxf(best, rowsum_all<COLS>(nn));
+        keep_best(rowsum_all<COLS>(nn), row);
     };
     if constexpr (NORM == 2) {
         if (maxonly) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
 #pragma unroll
             for (int i = 0; i < STAT_LT; ++i)
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) rowstat(t[i][ps]);
+                for (int ps = 0; ps < NPASS; ++ps) rowstat(t[i][ps], (light_c0 + i) * C + srow + ps * RPP);
         }
     }
     if (!maxonly) issue(c_begin * C);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
                     float nn = 0.f;
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) nn = fmaf(xk[e], xk[e], nn);
-                    best = fmaxf(best, rowsum_all<COLS>(nn));
+                    keep_best(rowsum_all<COLS>(nn), n0 + row);
                 }
                 stage_floats<DP, EPL, NP>(smem, KI, row, scol, xk);
             } else {
@@ -206,15 +210,19 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
         }
     }
     if constexpr (NORM == 2) {
-        __shared__ float wmax[NT / 64];
-        best = wave_max(best);
+        __shared__ unsigned long long wmax[NT / 64];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
         if (lane == 0) wmax[w] = best;
         __syncthreads();
         if (tid == 0) {
-            float m = wmax[0];
+            unsigned long long m = wmax[0];
 #pragma unroll
-            for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, wmax[i]);
-            prm.partials[((int64_t)(statq ? 0 : 1) * prm.BH + bh) * prm.pw + word] = __float_as_uint(m);
+            for (int i = 1; i < NT / 64; ++i) m = wmax[i] > m ? wmax[i] : m;
+            prm.partials[((int64_t)(statq ? 0 : 1) * prm.BH + bh) * prm.pw + word] = m;
         }
         if (maxonly) return;
     }
@@ -257,24 +265,31 @@ __global__ __launch_bounds__(256) void p1_state_prefix_kernel(float* state, int 
 // NORM = 2 companion: folds the statistic words into inv_q, inv_k = 1 / sqrt(max) (block 0 of a head writes them for the main
 // kernel) and runs the inclusive prefix with the K scale applied to what is linear in K: S2 and ksum (S1 = sum v is not)
 __global__ __launch_bounds__(256) void p1_state_prefix_scale_kernel(float* state, int nrec, int rec_floats, int dp,
-                                                                    const unsigned int* partials, int pw, int nq, int nk,
-                                                                    float* inv_q, float* inv_k) {
-    __shared__ float red[8];
+                                                                    const unsigned long long* partials, int pw, int nq, int nk,
+                                                                    float* inv_q, float* inv_k, int* nstar_q, int* nstar_k) {
+    __shared__ unsigned long long red[8];
     const int bh = blockIdx.y, BH = gridDim.y, tid = threadIdx.x;
-    // every block of a head folds K's words (a few dozen); block 0 also Q's and writes both for the main kernel
-    unsigned int mk = 0u, mq = 0u;
-    for (int j = tid; j < nk; j += 256) mk = max(mk, partials[((int64_t)BH + bh) * pw + j]);
+    // every block of a head folds K's keys (a few dozen); block 0 also Q's and writes both for the main kernel
+    unsigned long long mk = 0ull, mq = 0ull;
+    for (int j = tid; j < nk; j += 256) { const unsigned long long o = partials[((int64_t)BH + bh) * pw + j]; mk = o > mk ? o : mk; }
     if (blockIdx.x == 0)
-        for (int j = tid; j < nq; j += 256) mq = max(mq, partials[(int64_t)bh * pw + j]);
-    float fk = wave_max(__uint_as_float(mk)), fq = wave_max(__uint_as_float(mq));        // squared norms: non-negative floats
-    if ((tid & 63) == 0) { red[tid >> 6] = fk; red[4 + (tid >> 6)] = fq; }
+        for (int j = tid; j < nq; j += 256) { const unsigned long long o = partials[(int64_t)bh * pw + j]; mq = o > mq ? o : mq; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long ok = __shfl_xor(mk, off, 64), oq = __shfl_xor(mq, off, 64);
+        mk = ok > mk ? ok : mk;
+        mq = oq > mq ? oq : mq;
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = mk; red[4 + (tid >> 6)] = mq; }
     __syncthreads();
-    fk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    fq = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-    const float ksc = 1.0f / sqrtf(fk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mk = red[i] > mk ? red[i] : mk; mq = red[4 + i] > mq ? red[4 + i] : mq; }
+    const float ksc = 1.0f / sqrtf(__uint_as_float((unsigned)(mk >> 32)));          // squared norms: non-negative floats
     if (blockIdx.x == 0 && tid == 0) {
-        inv_q[bh] = 1.0f / sqrtf(fq);
+        inv_q[bh] = 1.0f / sqrtf(__uint_as_float((unsigned)(mq >> 32)));
         inv_k[bh] = ksc;
+        if (nstar_q) nstar_q[bh] = (int)(0xffffffffu - (unsigned)(mq & 0xffffffffull));
+        if (nstar_k) nstar_k[bh] = (int)(0xffffffffu - (unsigned)(mk & 0xffffffffull));
     }
     const int e = blockIdx.x * 256 + tid;
     if (e >= rec_floats) return;
@@ -310,7 +325,8 @@ size_t split_workspace_bytes(const fastmax_problem& p, int dp) {
 }
 
 template <int DP, typename TIN, int NORM, bool RS = false>
-static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr) {
+static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr,
+                          int* nstar_q = nullptr, int* nstar_k = nullptr) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL, RPP = 4 * DP / (DP / EPL);
     constexpr int lds = 2 * NP * 64 * DP * 2 + 2 * RPP * DP * 4;
     auto kern = p1_state_kernel<DP, TIN, NORM, RS>;
@@ -326,7 +342,7 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, fl
         const int nlq = (nchunks + STAT_LT - 1) / STAT_LT, nlk = (nchunks - last_c0 + STAT_LT - 1) / STAT_LT;
         hipLaunchKernelGGL(kern, dim3(BH * (prm.nseg - 1 + nlq + nlk)), dim3(4 * DP), lds, stream, prm);
         hipLaunchKernelGGL(p1_state_prefix_scale_kernel, dim3((rec + 255) / 256, BH), dim3(256), 0, stream, prm.state, prm.nseg - 1,
-                           rec, DP, prm.partials, prm.pw, nlq, prm.nseg - 1 + nlk, inv_q, inv_k);
+                           rec, DP, prm.partials, prm.pw, nlq, prm.nseg - 1 + nlk, inv_q, inv_k, nstar_q, nstar_k);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3(prm.nseg - 1, BH), dim3(4 * DP), lds, stream, prm);
@@ -336,9 +352,10 @@ static int launch_state_t(const StateParams& prm, int BH, hipStream_t stream, fl
     return (int)hipGetLastError();
 }
 template <typename TIN, int NORM>
-static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr) {
-    if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream, inv_q, inv_k);
-    return launch_state_t<128, TIN, NORM>(prm, BH, stream, inv_q, inv_k);
+static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t stream, float* inv_q = nullptr, float* inv_k = nullptr,
+                          int* nstar_q = nullptr, int* nstar_k = nullptr) {
+    if (dp == 64) return launch_state_t<64, TIN, NORM>(prm, BH, stream, inv_q, inv_k, nstar_q, nstar_k);
+    return launch_state_t<128, TIN, NORM>(prm, BH, stream, inv_q, inv_k, nstar_q, nstar_k);
 }
 
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
@@ -380,14 +397,14 @@ int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const f
 int launch_split_states_stats(const FwdArgs& a, const SplitPlan& plan, int dp) {
     const LinearmaxStats& st = *a.stats;
     StateParams prm{a.k, a.v, a.ks, a.vs, reinterpret_cast<float*>(a.workspace), nullptr, a.prob.H, a.prob.Nq, a.prob.D,
-                    plan.nseg, plan.cps, nullptr, nullptr, a.q, a.qs, st.partials, a.prob.B * a.prob.H,
+                    plan.nseg, plan.cps, nullptr, nullptr, a.q, a.qs, reinterpret_cast<unsigned long long*>(st.partials), a.prob.B * a.prob.H,
                     (a.prob.Nq + 255) / 256 + 32};
     const int BH = a.prob.B * a.prob.H;
     if (BH > 65535) return FASTMAX_E_BAD_SHAPE;
     switch (a.prob.in_dtype) {
-        case FASTMAX_F32: return launch_state_d<float, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
-        case FASTMAX_BF16: return launch_state_d<bf16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
-        case FASTMAX_F16: return launch_state_d<f16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k);
+        case FASTMAX_F32: return launch_state_d<float, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k, st.nstar_q, st.nstar_k);
+        case FASTMAX_BF16: return launch_state_d<bf16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k, st.nstar_q, st.nstar_k);
+        case FASTMAX_F16: return launch_state_d<f16_t, 2>(prm, BH, dp, a.stream, st.inv_q, st.inv_k, st.nstar_q, st.nstar_k);
     }
     return FASTMAX_E_BAD_DTYPE;
 }
@@ -397,6 +414,7 @@ int launch_split_states_stats(const FwdArgs& a, const SplitPlan& plan, int dp) {
 int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp) {
     const LinearmaxStats& st = *a.stats;
     if (plan.nseg > 1) return launch_split_states_stats(a, plan, dp);
+    // the paired statistics pass does not determine the rows n*: nstar_q / nstar_k keep what the caller put there (-1)
     return launch_normalize_stats2(a.q, a.qs, a.k, a.ks, a.prob.in_dtype, st.inv_q, st.inv_k, a.prob.B, a.prob.H, a.prob.Nq, a.prob.D,
                                    st.partials, a.stream);
 }

@@ -311,6 +311,34 @@ __global__ __launch_bounds__(64) void normalize_bwd_fix_kernel(const void* x, St
     store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
 }
 
+// The same fix-up for a gradient whose rows ALREADY carry inv (g - mean_D g) (written by the scan kernel that produced g, which also
+// left the partial sums): the dL/dM term is added to row n* in place, gx[n*] += dLdM (x_n* - mean) inv.  One wave per head.
+template <typename T, int LPR>
+__global__ __launch_bounds__(64) void normalize_bwd_fixadd_kernel(const void* x, Strides3 xs, const float* inv_norm, const float* part_dot,
+                                                                  const int* nstar, int nblk, int H, int N, int D, T* gx, int vec) {
+    constexpr int EPL = 16 / sizeof(T);
+    const int tid = threadIdx.x, sub = tid % LPR;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const float inv = inv_norm[bh], invD = 1.0f / (float)D;
+    float S = 0.f;
+    for (int i = tid; i < nblk; i += 64) S += part_dot[(int64_t)bh * nblk + i];
+    S = wave_sum(S);
+    const int n = nstar[bh];                                       // the row that attains the max-norm (the forward found it)
+    const float dLdM = -(S * inv) * inv;
+    if (tid >= LPR || n < 0 || n >= N) return;
+    float v[EPL], gv[EPL];
+    load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);
+    load_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
+    const float mean = group_sum<LPR>(s) * invD;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+        if (sub * EPL + e < D) gv[e] = fmaf(dLdM, (v[e] - mean) * inv, gv[e]);
+    store_row_piece<T>(gx + ((int64_t)bh * N + n) * D, sub, D, vec, gv);
+}
+
 static int nrm_vec_ok(const void* x, Strides3 xs, size_t es, int D) {
     const int epl = (int)(16 / es);
     return (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ((xs.sb * es) % 16 == 0) && ((xs.sh * es) % 16 == 0) &&
@@ -401,6 +429,28 @@ static int normalize_bwd_t(const void* x, Strides3 xs, const void* gy, const flo
 #undef CALL
     return (int)hipGetLastError();
 }
+template <typename T>
+static int normalize_fixadd_t(const void* x, Strides3 xs, const float* inv_norm, const float* part_dot, const int* nstar,
+                              int nblk, int B, int H, int N, int D, void* gx, hipStream_t stream) {
+    const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl;
+    if (need > 64) return FASTMAX_E_BAD_SHAPE;
+    const int vec = nrm_vec_ok(x, xs, sizeof(T), D) && !(reinterpret_cast<uintptr_t>(gx) & 15);
+#define CALL(L) hipLaunchKernelGGL((normalize_bwd_fixadd_kernel<T, L>), dim3(B * H), dim3(64), 0, stream, x, xs, inv_norm, part_dot, nstar, nblk, H, N, D, reinterpret_cast<T*>(gx), vec)
+    NRM_LPR_SWITCH(need, CALL)
+#undef CALL
+    return (int)hipGetLastError();
+}
+// gx rows already hold inv (g - mean g): add the dL/dM term to the row that attains the max-norm (partials from the scan kernel)
+int launch_normalize_fixadd(const void* x, Strides3 xs, int dtype, const float* inv_norm, const float* part_dot,
+                            const int* nstar, int nblk, int B, int H, int N, int D, void* gx, hipStream_t stream) {
+    switch (dtype) {
+        case FASTMAX_F32: return normalize_fixadd_t<float>(x, xs, inv_norm, part_dot, nstar, nblk, B, H, N, D, gx, stream);
+        case FASTMAX_BF16: return normalize_fixadd_t<bf16_t>(x, xs, inv_norm, part_dot, nstar, nblk, B, H, N, D, gx, stream);
+        case FASTMAX_F16: return normalize_fixadd_t<f16_t>(x, xs, inv_norm, part_dot, nstar, nblk, B, H, N, D, gx, stream);
+    }
+    return FASTMAX_E_BAD_DTYPE;
+}
+
 int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void* gy, const float* inv_norm, void* gx, int B, int H,
                               int N, int D, void* ws, hipStream_t stream, int rep) {
     if (rep < 1) return FASTMAX_E_BAD_SHAPE;

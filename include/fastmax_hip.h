@@ -196,8 +196,12 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob,
                                        const void* k, const int64_t* k_strides,
                                        const void* v, const int64_t* v_strides,
                                        float* q_inv_norm, float* k_inv_norm,
+                                       int* q_nstar, int* k_nstar,
                                        void* o, float* g,
                                        void* workspace, size_t workspace_bytes, void* stream);
+/*      q_nstar / k_nstar (B*H ints each, or NULL): the row that attains the max-norm, per head -- written only when the
+ *      statistics rode on the state pass (the caller pre-sets -1); fastmax_hip_linearmax_backward's fused prologue backward
+ *      needs k_nstar.                                                                                                      */
 
 /*      Training route of the same branch (masked, p = 1): the backward of fastmax_hip_linearmax_forward_auto.  q, k are the RAW
  *      tensors and q_inv_norm / k_inv_norm what the forward left; the linear-time scans apply the prologue while staging (as the
@@ -213,10 +217,13 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob,
                                    const void* v, const int64_t* v_strides,
                                    const void* o, const float* g,
                                    const void* grad_o, const int64_t* go_strides,
-                                   const float* q_inv_norm, const float* k_inv_norm,
+                                   const float* q_inv_norm, const float* k_inv_norm, const int* k_nstar,
                                    void* dq, void* dk, void* dv,
                                    void* workspace, size_t workspace_bytes,
-                                   const void* fwd_states, size_t fwd_state_bytes, void* stream);
+                                   const void* fwd_states, size_t fwd_state_bytes, int flags, void* stream);
+/*      flags bit 0 (needs k_nstar with every entry >= 0): dk leaves as the gradient wrt the RAW k (the dK/dV kernel applies
+ *      inv (g - mean_D g) to its tile and a one-row fix-up adds the dL/dM term to row n*): no normalize_backward call for k.
+ *      Only when every query head has its own k head.                                                                     */
 
 
 /* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:

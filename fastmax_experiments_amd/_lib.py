@@ -112,7 +112,7 @@ def lib():
     L.fastmax_hip_linearmax_forward_auto_workspace.restype = sz
     L.fastmax_hip_linearmax_train_supported.argtypes = [pp]
     L.fastmax_hip_linearmax_train_supported.restype = ci
-    L.fastmax_hip_linearmax_backward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, i64p, fp, fp, vp, vp, vp, vp, vp, sz, vp, sz, ci, vp]
+    L.fastmax_hip_linearmax_backward.argtypes = [pp, vp, i64p, vp, i64p, vp, i64p, vp, fp, vp, i64p, fp, fp, vp, vp, vp, vp, vp, vp, sz, vp, sz, ci, vp]
     L.fastmax_hip_linearmax_backward.restype = ci
     i64 = ctypes.c_int64
     L.fastmax_hip_decode_state_bytes.argtypes = [ci, ci, ci]

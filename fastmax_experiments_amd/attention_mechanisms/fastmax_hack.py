@@ -62,7 +62,8 @@ class _NormalizeQK(torch.autograd.Function):
 
 
 FUSED_TRAINING = os.environ.get("FASTMAX_LINEARMAX_FUSED_TRAIN", "1") != "0"
-FUSED_PROLOGUE_BWD = os.environ.get("FASTMAX_LINEARMAX_FUSED_PROLOGUE_BWD", "1") != "0"     # k side, inside the dK/dV kernel
+# the prologue's backward inside the scan kernels: 0 off, 1 the k side (dK/dV kernel), 3 both sides (default)
+FUSED_PROLOGUE_BWD = int(os.environ.get("FASTMAX_LINEARMAX_FUSED_PROLOGUE_BWD", "3"))
 
 
 class _LinearmaxP1(torch.autograd.Function):
@@ -83,10 +84,10 @@ class _LinearmaxP1(torch.autograd.Function):
         r = ops.linearmax_forward_fused(q, kv, v, train=True)
         if r is None:
             raise NotImplementedError("fused linearmax training route does not cover this problem")
-        o, g, inv_q, inv_k, states, k_nstar = r
+        o, g, inv_q, inv_k, states, nstar = r
         ctx.save_for_backward(q, k, v, o, g, inv_q, inv_k)
         ctx.states, ctx.rep = states, rep
-        ctx.k_nstar = k_nstar if (rep == 1 and FUSED_PROLOGUE_BWD) else None
+        ctx.nstar = nstar if (rep == 1 and FUSED_PROLOGUE_BWD) else None
         return o
 
     @staticmethod
@@ -98,12 +99,14 @@ class _LinearmaxP1(torch.autograd.Function):
             B, G, N, D = k.shape
             kv = k.view(B * G, 1, N, D).expand(B * G, rep, N, D)
         go = ops._prep(go.to(q.dtype), q.device)
-        fuse_k = ctx.k_nstar is not None
-        dqn, dkn, dv = ops.linearmax_backward(q, kv, v, o, g, go, inv_q, inv_k, ctx.states, k_nstar=ctx.k_nstar)
-        ctx.states = ctx.k_nstar = None
+        fused = ctx.nstar is not None        # both scan kernels apply the prologue's backward to their tiles
+        dqn, dkn, dv = ops.linearmax_backward(q, kv, v, o, g, go, inv_q, inv_k, ctx.states, nstar=ctx.nstar, fuse=FUSED_PROLOGUE_BWD)
+        ctx.states = ctx.nstar = None
+        if fused and FUSED_PROLOGUE_BWD == 3:
+            return dqn, dkn, dv, None
         dq = ops.normalize_backward(q, dqn, inv_q.view(q.shape[0], q.shape[1]), 1)
-        if fuse_k:
-            dk = dkn                     # the dK/dV kernel applied the prologue's backward to its tile
+        if fused:
+            dk = dkn
         elif rep > 1:
             B, G, N, D = k.shape
             inv_g = inv_k.view(B * G, rep)[:, 0].contiguous().view(B, G)

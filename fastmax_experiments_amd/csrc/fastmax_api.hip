@@ -397,7 +397,7 @@ int fastmax_hip_linearmax_train_supported(const fastmax_problem* prob) {
 int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                    const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o, const float* g,
                                    const void* grad_o, const int64_t* go_strides, const float* q_inv_norm, const float* k_inv_norm,
-                                   const int* k_nstar, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
+                                   const int* q_nstar, const int* k_nstar, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes,
                                    const void* fwd_states, size_t fwd_state_bytes, int flags, void* stream) {
     int rc = validate(prob);
     if (rc) return rc;
@@ -413,8 +413,9 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, c
               workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
     a.qscale = q_inv_norm;
     a.kscale = k_inv_norm;
-    a.fuse_prologue = (flags & 1) && k_nstar;
+    a.fuse_prologue = ((flags & 1) && k_nstar ? 1 : 0) | ((flags & 3) == 3 && k_nstar && q_nstar ? 2 : 0);
     a.k_nstar = k_nstar;
+    a.q_nstar = q_nstar;
     const SplitPlan plan = split_plan(*prob);
     if (fwd_states && plan.nseg > 1 && fwd_state_bytes >= split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128) &&
         !(reinterpret_cast<uintptr_t>(fwd_states) & 15))

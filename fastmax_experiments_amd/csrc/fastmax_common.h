@@ -108,6 +108,7 @@ struct BwdArgs {
     const float *qscale = nullptr, *kscale = nullptr;
     int fuse_prologue = 0;               // bit 0: dk leaves as the gradient wrt the raw k (prologue backward inside the dK/dV kernel)
     const int* k_nstar = nullptr;        //        the row of k that attains the max-norm, per head (from the forward)
+    const int* q_nstar = nullptr;        // bit 1: the same for dq / q (needs bit 0: the dK/dV kernel leaves the shared sum)
 };
 
 int launch_fwd_quadratic(const FwdArgs& a);

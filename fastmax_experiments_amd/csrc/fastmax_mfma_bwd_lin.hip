@@ -33,6 +33,7 @@ struct LinBwdParams {
     // [bh][nseg] entries
     float* kpart_dot;
     const int* k_nstar;             // the row of k that attains the max-norm, per head (found by the forward's statistics)
+    const int* q_nstar;             // FUSEQ: the same for q (dq leaves as the gradient wrt the raw q)
 };
 
 // Stage a wave's 16 x W fp32 accumulator tile (lane = row r, acc[t][reg] = column 16t + 4q4 + reg) through a wave-private
@@ -85,8 +86,9 @@ template <int DP, int SP, int TW> __device__ __forceinline__ void publish_state(
 // NW = 4: wave w owns query tile w and every output column.  NW = 8 (the variants whose LDS footprint allows one workgroup
 // per CU only): wave (wq = w & 3, hf = w >> 2) owns query tile wq and the column half hf of dQ and of the S2 state; the
 // 64 x 64 score-shaped tile is computed by both halves.
-template <int DP, typename TIN, int NW, bool NORM, bool BUF>
+template <int DP, typename TIN, int NW, bool NORM, bool BUF, bool FUSEQ = false>
 __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dq_kernel(LinBwdParams prm) {
+    static_assert(!FUSEQ || NORM, "the fused prologue backward belongs to the linearmax route");
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     constexpr int C = 64, IMG = C * DP * 2, SIMG = DP * DP * 2, SP = NP;
     constexpr int KI = 0, VI = NP * IMG, GI = 2 * NP * IMG, S2I = 3 * NP * IMG;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
     constexpr int NT = 64 * NW, HF = NW / 4;
     constexpr int COLS = DP / EPL, RPP = NT / COLS, NPASS = C / RPP;
     constexpr int PARTK = KSUM + 2 * DP * 4, CS = PARTK + RPP * DP * 4, WS = CS + 256, OST = WS + 256;
+    constexpr int RSQ = OST + (NW == 8 ? 8 * 16 * (DP / 2) * 4 : 0);           // FUSEQ: NW x 16 row sums of the dQ tile
     constexpr int KS = DP / 32, NSL = DP / 64;     // NSL state row slabs (16 rows) per wave
     constexpr int MT = (DP / 16) / HF, DT = (DP / 16) / HF;                  // column tiles of this wave (dQ columns m, S2 columns d)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -277,15 +280,46 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
                 for (int sl = 0; sl < NSL; ++sl) s2acc[sl][dt] = mfma_parts<NP, NP>(vtf, kf[sl], s2acc[sl][dt]);
             }
         }
+        // FUSEQ: the prologue's row-wise backward on the dQ tile -- dq_raw = inv_q (dq' - mean_D dq'), dq' = a w_i acc (the dL/dM
+        // term of row n* is added by the fix-up pass).  The row sum of a lane's columns, across q4 by shuffles, across the two
+        // column halves (NW = 8) through LDS and B2: the store then happens after B2 (its staging area is wave-private).
+        float qrs = 0.f, oscale = prm.a * wi;
+        if constexpr (FUSEQ) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qrs += acc[mt][i];
+            qrs += __shfl_xor(qrs, 16, 64);
+            qrs += __shfl_xor(qrs, 32, 64);
+            oscale *= prm.qscale[bh];
+            if constexpr (NW == 8) {
+                if (q4 == 0) reinterpret_cast<float*>(smem + RSQ)[16 * w + r] = qrs;
+            } else {
+                const float qmean = qrs * invD;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mt][i] -= qmean;                    // padded columns are not stored
+            }
+        }
         if constexpr (NW == 4) {
             // dQ rows, staged in the gradient dtype through this wave's own (already consumed) G image rows
-            store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, prm.a * wi,
+            store_tile16_private<DP, sizeof(TIN)>(smem + GI + 16 * w * (2 * DP), smem + GI + IMG + 16 * w * (2 * DP), acc, oscale,
                                                   lane, prm.dq, prm.grad_dtype, ((int64_t)bh * N + n0 + 16 * w) * D, n0 + 16 * w, N, D);
-        } else {
-            store_cols16<16 * MT>(smem + OST + w * (16 * 16 * MT * 4), acc, prm.a * wi, lane, prm.dq, prm.grad_dtype,
+        } else if constexpr (!FUSEQ) {
+            store_cols16<16 * MT>(smem + OST + w * (16 * 16 * MT * 4), acc, oscale, lane, prm.dq, prm.grad_dtype,
                                   ((int64_t)bh * N + n0 + 16 * wq) * D, 16 * t0, n0 + 16 * wq, N, D);
         }
         __syncthreads();                                             // B2
+        if constexpr (FUSEQ && NW == 8) {
+            const float qmean = (qrs + reinterpret_cast<const float*>(smem + RSQ)[16 * (w ^ 4) + r]) * invD;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[mt][i] -= qmean;
+            store_cols16<16 * MT>(smem + OST + w * (16 * 16 * MT * 4), acc, oscale, lane, prm.dq, prm.grad_dtype,
+                                  ((int64_t)bh * N + n0 + 16 * wq) * D, 16 * t0, n0 + 16 * wq, N, D);
+        }
         if (c + 1 < c_end) {
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) publish_state<DP, SP, DT>(smem, S2I, SIMG, s2acc[sl], 1.0f, 16 * (wq + 4 * sl) + r, q4, t0);
@@ -591,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
         __syncthreads();
     }
     if constexpr (FUSEK) {
-        // one record per block: sum_n dk'_n . xc_n (xc = y / inv), for the one-row fix-up
+        // one record per block: T = sum_n dk'_n . y_n (= sum_n dq'_n . y^q_n = sum_ij dS_ij s_ij), for the one-row fix-ups
         kdot = wave_sum(kdot);
         float* fd = reinterpret_cast<float*>(smem + RSUM);
         if (lane == 0) fd[w] = kdot;
@@ -599,12 +633,12 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
         if (tid == 0) {
             float sd = 0.f;
             for (int i = 0; i < NW; ++i) sd += fd[i];
-            prm.kpart_dot[(int64_t)bh * prm.nseg + seg] = sd / prm.kscale[bh];
+            prm.kpart_dot[(int64_t)bh * prm.nseg + seg] = sd;          // T = sum dS . s: the same number for the q side
         }
     }
 }
 
-template <int DP, typename TIN, bool NORM, bool BUF, bool FUSEK>
+template <int DP, typename TIN, bool NORM, bool BUF, bool FUSEK, bool FUSEQ = false>
 static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
@@ -612,11 +646,11 @@ static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream,
     constexpr int NWQ = DP == 64 ? 4 : 8, NWKV = (DP == 64 && NP == 1) ? 4 : 8;
     constexpr int RPPQ = 64 * NWQ / (DP / EPL), RPPKV = 64 * NWKV / (DP / EPL);
     constexpr int IMG = 64 * DP * 2, SIMG = DP * DP * 2;
-    constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPPQ * DP * 4 + 512 + (NWQ == 8 ? 8 * 16 * (DP / 2) * 4 : 0);
+    constexpr int lds_q = 3 * NP * IMG + NP * SIMG + 2 * DP * 4 + RPPQ * DP * 4 + 512 + (NWQ == 8 ? 8 * 16 * (DP / 2) * 4 : 0) + 512;
     constexpr int lds_kv = 4 * NP * IMG + NP * SIMG + 4 * DP * 4 + 2 * RPPKV * DP * 4 + 256 + 640;
     static_assert(lds_kv <= 160 * 1024 && lds_q <= 160 * 1024, "LDS budget");
     static_assert(NWKV == 4 || 8 * 2 * 16 * (DP / 2) * 4 <= 4 * NP * IMG, "dK/dV staging areas fit the freed images");
-    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM, BUF>;
+    auto kq = bwd_p1_dq_kernel<DP, TIN, NWQ, NORM, BUF, FUSEQ>;
     auto kkv = bwd_p1_dkv_kernel<DP, TIN, NWKV, NORM, BUF, FUSEK>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -633,9 +667,16 @@ static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
-    if constexpr (FUSEK)
-        return launch_normalize_fixadd(prm.k, prm.ks, prob.in_dtype, prm.kscale, prm.kpart_dot, prm.k_nstar, prm.nseg, prob.B, prob.H,
-                                       prm.N, prm.D, prm.dk, stream);
+    if constexpr (FUSEK) {
+        int rc = launch_normalize_fixadd(prm.k, prm.ks, prob.in_dtype, prm.kscale, prm.kpart_dot, prm.k_nstar, prm.nseg, prob.B, prob.H,
+                                         prm.N, prm.D, prm.dk, stream);
+        if constexpr (FUSEQ) {
+            if (rc) return rc;
+            rc = launch_normalize_fixadd(prm.q, prm.qs, prob.in_dtype, prm.qscale, prm.kpart_dot, prm.q_nstar, prm.nseg, prob.B, prob.H,
+                                         prm.N, prm.D, prm.dq, stream);
+        }
+        return rc;
+    }
     return (int)hipGetLastError();
 }
 
@@ -646,6 +687,8 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     const bool buf = quad32_span_ok(prm.qs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.ks.sn, prm.N, prm.D, es) &&
                      quad32_span_ok(prm.vs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.gos.sn, prm.N, prm.D, es);
     if constexpr (NORM) {
+        if (prm.kpart_dot && prm.q_nstar)
+            return buf ? launch_lin_bwd_b<DP, TIN, true, true, true, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, true, true>(prm, BH, stream, prob);
         if (prm.kpart_dot) return buf ? launch_lin_bwd_b<DP, TIN, true, true, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, true>(prm, BH, stream, prob);
     }
     return buf ? launch_lin_bwd_b<DP, TIN, NORM, true, false>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false, false>(prm, BH, stream, prob);
@@ -683,10 +726,11 @@ int launch_bwd_lin(const BwdArgs& a) {
     float* rstate = reinterpret_cast<float*>(ws + coff + sbytes);
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                      cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
-                     fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale, nullptr, nullptr};
+                     fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale, nullptr, nullptr, nullptr};
     if ((a.fuse_prologue & 1) && a.qscale && a.kscale && a.k_nstar) {
         prm.kpart_dot = reinterpret_cast<float*>(ws + coff + 2 * sbytes);
         prm.k_nstar = a.k_nstar;
+        if (a.fuse_prologue & 2) prm.q_nstar = a.q_nstar;
     }
     const int BH = a.prob.B * a.prob.H;
     if (plan.nseg > 1 && !a.fwd_states) {

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(64) void normalize_bwd_fixadd_kernel(const void* x,
     for (int i = tid; i < nblk; i += 64) S += part_dot[(int64_t)bh * nblk + i];
     S = wave_sum(S);
     const int n = nstar[bh];                                       // the row that attains the max-norm (the forward found it)
-    const float dLdM = -(S * inv) * inv;
+    // part_dot holds T = sum_n g_n . y_n (y = xc inv): dL/dM = -(T / inv) inv^2 = -T inv
+    const float dLdM = -S * inv;
     if (tid >= LPR || n < 0 || n >= N) return;
     float v[EPL], gv[EPL];
     load_row_piece<T>(row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n), sub, D, vec, v);

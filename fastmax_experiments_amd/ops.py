@@ -213,8 +213,8 @@ def linearmax_forward_fused(q, k, v, return_stats=False, train=False):
     """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
     Returns None when the shape / dtype is not covered (the caller then uses the unfused route).
     ``train``: -> (o, g, inv_q, inv_k, states, k_nstar) for linearmax_backward (states = the forward's workspace when it holds
-    the sequence split's prefix states, else None; k_nstar = per head the row of k that attains the max-norm, or None when the
-    statistics did not ride on the state pass)."""
+    the sequence split's prefix states, else None; nstar (2, B*H) = per head the row of q / of k that attains the max-norm, or
+    None when the statistics did not ride on the state pass)."""
     L = _lib.lib()
     dev = q.device
     B, H, N, D = q.shape
@@ -246,14 +246,15 @@ def linearmax_forward_fused(q, k, v, return_stats=False, train=False):
             nb = L.fastmax_hip_forward_state_bytes(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
                                                    v.data_ptr(), _strides(v), o.data_ptr())
         split = L.fastmax_hip_forward_workspace(ctypes.byref(prob)) > 0           # the statistics rode on the state pass
-        return o, g, stats[0], stats[1], (wsb if 0 < nb <= wsb.numel() else None), (nstar[1] if split else None)
+        return o, g, stats[0], stats[1], (wsb if 0 < nb <= wsb.numel() else None), (nstar if split else None)
     return (o, stats[0], stats[1]) if return_stats else o
 
 
-def linearmax_backward(q, k, v, o, g, grad_o, inv_q, inv_k, states=None, k_nstar=None):
+def linearmax_backward(q, k, v, o, g, grad_o, inv_q, inv_k, states=None, nstar=None, fuse=0):
     """backward of linearmax_forward_fused(train=True): q, k RAW, the scans apply the prologue while staging.
-    -> (dq_n, dk_n, dv): gradients wrt the NORMALISED q, k (finish with normalize_backward) and wrt v; with ``k_nstar`` (from
-    the forward) the dK/dV kernel applies the prologue's backward itself and dk_n is the gradient wrt the raw k."""
+    -> (dq_n, dk_n, dv): gradients wrt the NORMALISED q, k (finish with normalize_backward) and wrt v.  With ``nstar`` (from
+    the forward) and ``fuse`` bit 0 the dK/dV kernel applies the prologue's backward itself and dk_n is the gradient wrt the raw
+    k; bit 1 (with bit 0): the dQ kernel does the same for dq_n."""
     L = _lib.lib()
     dev = q.device
     prob = _problem(q, k, q.dtype, o.dtype, 1, True, 1.0, 0.0)
@@ -265,10 +266,11 @@ def linearmax_backward(q, k, v, o, g, grad_o, inv_q, inv_k, states=None, k_nstar
         rc = L.fastmax_hip_linearmax_backward(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
                                               v.data_ptr(), _strides(v), o.data_ptr(), g.data_ptr(), grad_o.data_ptr(),
                                               _strides(grad_o), inv_q.data_ptr(), inv_k.data_ptr(),
-                                              None if k_nstar is None else k_nstar.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                              None if nstar is None else nstar[0].data_ptr(),
+                                              None if nstar is None else nstar[1].data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                               dv.data_ptr(), wsp, wsb.numel() if wsb is not None else 0,
                                               None if states is None else states.data_ptr(),
-                                              0 if states is None else states.numel(), 0 if k_nstar is None else 1, _stream(dev))
+                                              0 if states is None else states.numel(), 0 if nstar is None else fuse, _stream(dev))
     _lib.check(rc, "fastmax_hip_linearmax_backward")
     return dq, dk, dv
 

@@ -217,13 +217,15 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob,
                                    const void* v, const int64_t* v_strides,
                                    const void* o, const float* g,
                                    const void* grad_o, const int64_t* go_strides,
-                                   const float* q_inv_norm, const float* k_inv_norm, const int* k_nstar,
+                                   const float* q_inv_norm, const float* k_inv_norm,
+                                   const int* q_nstar, const int* k_nstar,
                                    void* dq, void* dk, void* dv,
                                    void* workspace, size_t workspace_bytes,
                                    const void* fwd_states, size_t fwd_state_bytes, int flags, void* stream);
 /*      flags bit 0 (needs k_nstar with every entry >= 0): dk leaves as the gradient wrt the RAW k (the dK/dV kernel applies
  *      inv (g - mean_D g) to its tile and a one-row fix-up adds the dL/dM term to row n*): no normalize_backward call for k.
- *      Only when every query head has its own k head.                                                                     */
+ *      Only when every query head has its own k head.  flags bit 1 (with bit 0, needs q_nstar): the same for dq / q -- the
+ *      number both fix-ups need, sum_ij dS_ij s_ij, is one and the same and comes out of the dK/dV kernel.                */
 
 
 /* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:

@@ -719,12 +719,15 @@ def _prologue_chain_fp64(x, gyn):
 
 
 @pytest.mark.parametrize("dt,tf,tb", [(torch.float32, 2 * TOL_FWD, 4 * TOL_BWD), (torch.bfloat16, 1.6e-2, 3e-2), (torch.float16, 3e-3, 8e-3)])
-@pytest.mark.parametrize("shape", [(1, 2, 1024, 64), (2, 3, 700, 32), (1, 2, 2100, 128), (1, 40, 512, 64), (1, 2, 600, 48)])
+@pytest.mark.parametrize("shape", [(1, 2, 1024, 64), (2, 3, 700, 32), (1, 2, 2100, 128), (1, 40, 512, 64), (1, 2, 600, 48), (8, 48, 512, 32)])
 def test_linearmax_training_route_with_the_prologue_inside_the_scans(shape, dt, tf, tb):
     """masked p=1 linearmax with gradients, N >= 512: ONE autograd node on the raw q, k, v (fastmax_hip_linearmax_forward_auto +
     fastmax_hip_linearmax_backward: the scans normalise while staging, no normalised copy is stored) against the C oracle's scan
     on float64-normalised inputs with the chain rule through the prologue, and against the two-node route (normalize_cast +
-    fastmax) it replaces.  D = 128 exists for bf16 only (other dtypes keep the two-node route there: also checked)."""
+    fastmax) it replaces.  D = 128 exists for bf16 only (other dtypes keep the two-node route there: also checked).  With the
+    sequence split (few heads) the forward's statistics carry the rows n* and BOTH scan kernels apply the prologue's backward
+    to their own tiles (dq, dk leave as gradients wrt the raw tensors; one-row fix-ups add the dL/dM term); the last shape has
+    enough heads to run without the split: there the prologue's backward stays its own pass."""
     import importlib
     fh = importlib.import_module("fastmax_experiments_amd.attention_mechanisms.fastmax_hack")      # the module, not the function
     from oracle import c_oracle, fastmax_oracle as orc

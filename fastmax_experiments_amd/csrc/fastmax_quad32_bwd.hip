@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
         gload.load(it, rg);
         if (tid < 64) {
             const int gi = it * 64 + tid, gc = gi < Nq ? gi : Nq - 1;
-            rcw = -prm.cw[(int64_t)bh * Nq + gc];
+            rcw = prm.cw[(int64_t)bh * Nq + gc];         // raw: negated in commit() -- any arithmetic here needs the value at once,
+                                                          // i.e. an s_waitcnt vmcnt(0) right behind the tile requests
         }
     };
     auto commit = [&](int stage) __attribute__((always_inline)) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
                 stage_piece<DP, TIN, SWT>(smem, stage * STAGE + TRO + NP * IMGT, srow + ps * RPP, scol, rg[ps]);
             }
         }
-        if (tid < 64) reinterpret_cast<float*>(smem + stage * STAGE + CWO)[tid] = rcw;
+        if (tid < 64) reinterpret_cast<float*>(smem + stage * STAGE + CWO)[tid] = -rcw;
     };
     const int nqt = (Nq + 63) / 64;
     const int it0 = causal ? min(j0 / 64, nqt) : 0;

@@ -113,6 +113,8 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
     float ksc_c = 0.f;
     if constexpr (NORM) ksc_c = scol * EPL < D ? prm.kscale[bh] : 0.f;
     const float invD = 1.0f / (float)D;
+    float qinv = 1.f;                                            // FUSEQ: the head's 1 / max-norm of q, a scalar read once
+    if constexpr (FUSEQ) qinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, prm.qscale[bh])));
 
     // o is contiguous (B,H,N,D) in the input dtype on the masked path (dtype rule Q1)
     const TIN* ob = reinterpret_cast<const TIN*>(prm.o) + (int64_t)bh * N * D;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
                 for (int i = 0; i < 4; ++i) qrs += acc[mt][i];
             qrs += __shfl_xor(qrs, 16, 64);
             qrs += __shfl_xor(qrs, 32, 64);
-            oscale *= prm.qscale[bh];
+            oscale *= qinv;
             if constexpr (NW == 8) {
                 if (q4 == 0) reinterpret_cast<float*>(smem + RSQ)[16 * w + r] = qrs;
             } else {
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
         __syncthreads();                                             // B2
         if constexpr (FUSEK) {
             if constexpr (NW == 8) krs += reinterpret_cast<const float*>(smem + RSUM)[16 * (w ^ 4) + r];     // the other column half
-            const float kmean = krs * invD, kinv = prm.kscale[bh];
+            const float kmean = krs * invD, kinv = prm.kscale[bh];     // read here: one more live value across the loop spills at D = 128
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll

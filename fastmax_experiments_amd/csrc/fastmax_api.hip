@@ -252,7 +252,7 @@ int fastmax_hip_normalize_stats(const void* x, const int64_t* x_strides, int dty
 }
 
 size_t fastmax_hip_normalize_stats2_workspace(int B, int H, int N) {
-    return sizeof(unsigned int) * 2 * (size_t)B * H * (size_t)((N + 255) / 256);
+    return sizeof(unsigned long long) * 2 * (size_t)B * H * (size_t)((N + 255) / 256);          // (value, row) keys
 }
 
 int fastmax_hip_normalize_stats2(const void* x0, const int64_t* x0_strides, const void* x1, const int64_t* x1_strides, int dtype,

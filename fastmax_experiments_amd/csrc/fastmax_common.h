@@ -140,7 +140,7 @@ int launch_normalize_backward(const void* x, Strides3 xs, int dtype, const void*
 int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_norm, int B, int H, int N, int D,
                            void* workspace, hipStream_t stream);
 int launch_normalize_stats2(const void* x0, Strides3 s0, const void* x1, Strides3 s1, int dtype, float* inv0, float* inv1, int B, int H,
-                            int N, int D, void* ws, hipStream_t stream);
+                            int N, int D, void* ws, hipStream_t stream, int* nstar0 = nullptr, int* nstar1 = nullptr);
 // sequence split of the linear-time kernels when B*H alone cannot fill the chip
 struct SplitPlan { int nseg, cps; };
 SplitPlan split_plan(const fastmax_problem& p);

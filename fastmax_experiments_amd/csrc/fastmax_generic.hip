@@ -685,13 +685,13 @@ int launch_normalize_stats(const void* x, Strides3 xs, int dtype, float* inv_nor
 struct Max2Params {
     const void* x[2];
     Strides3 xs[2];
-    unsigned int* partials;      // [2][B*H][npart]
+    unsigned long long* partials;      // [2][B*H][npart] keys: (bits of max ||row - mean||^2) << 32 | ~row
     int H, N, D, vec[2];
 };
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void normalize_max2_kernel(Max2Params prm) {
     constexpr int TOK = 256, EPL = 16 / sizeof(T), RPB = 256 / LPR;
-    __shared__ float wmax[4];
+    __shared__ unsigned long long wmax[4];
     const int which = blockIdx.z;
     const void* x = prm.x[which];
     const Strides3 xs = prm.xs[which];
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void normalize_max2_kernel(Max2Params prm) {
     const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
     const int N = prm.N, D = prm.D;
     const int n_begin = blockIdx.x * TOK, n_end = min(N, n_begin + TOK);
-    float best = 0.f;
+    unsigned long long best = 0ull;                               // largest norm, lowest row on ties
     for (int n = n_begin + rgrp; n < n_end; n += RPB) {
         const T* row = row_ptr<T>(x, xs.sb, xs.sh, xs.sn, b, h, n);
         float v[EPL];
@@ -730,28 +730,39 @@ __global__ __launch_bounds__(256) void normalize_max2_kernel(Max2Params prm) {
         }
 #pragma unroll
         for (int off = 1; off < LPR; off <<= 1) nn += __shfl_xor(nn, off, 64);
-        best = fmaxf(best, nn);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(nn) << 32) | (unsigned long long)(0xffffffffu - (unsigned)n);
+        best = key > best ? key : best;
     }
-    best = wave_max(best);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
     if (lane == 0) wmax[wave] = best;
     __syncthreads();
-    if (tid == 0)
-        prm.partials[((int64_t)which * gridDim.y + bh) * gridDim.x + blockIdx.x] =
-            __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+    if (tid == 0) {
+        unsigned long long m = wmax[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+        prm.partials[((int64_t)which * gridDim.y + bh) * gridDim.x + blockIdx.x] = m;
+    }
 }
-// inv[i] = 1 / sqrt(max over the npart words of row i); rows = 2 B H (q heads, then k heads)
-__global__ void normalize_finish_partials_kernel(const unsigned int* partials, int npart, float* inv0, float* inv1, int nheads) {
+// inv[i] = 1 / sqrt(max over the npart keys of row i), nstar[i] = the row that attains it; rows = 2 B H (q heads, then k heads)
+__global__ void normalize_finish_partials_kernel(const unsigned long long* partials, int npart, float* inv0, float* inv1, int nheads,
+                                                 int* nstar0, int* nstar1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * nheads) return;
-    unsigned int m = 0u;
-    for (int j = 0; j < npart; ++j) m = max(m, partials[(int64_t)i * npart + j]);
-    (i < nheads ? inv0 : inv1)[i % nheads] = 1.0f / sqrtf(__uint_as_float(m));
+    unsigned long long m = 0ull;
+    for (int j = 0; j < npart; ++j) { const unsigned long long o = partials[(int64_t)i * npart + j]; m = o > m ? o : m; }
+    (i < nheads ? inv0 : inv1)[i % nheads] = 1.0f / sqrtf(__uint_as_float((unsigned)(m >> 32)));
+    int* ns = i < nheads ? nstar0 : nstar1;
+    if (ns) ns[i % nheads] = (int)(0xffffffffu - (unsigned)(m & 0xffffffffull));
 }
 template <typename T>
 static int launch_stats2_t(const void* x0, Strides3 s0, const void* x1, Strides3 s1, float* inv0, float* inv1, int B, int H, int N,
-                           int D, void* ws, hipStream_t stream) {
+                           int D, void* ws, hipStream_t stream, int* nstar0, int* nstar1) {
     const int epl = (int)(16 / sizeof(T)), need = (D + epl - 1) / epl, npart = (N + 255) / 256;
-    Max2Params prm{{x0, x1}, {s0, s1}, reinterpret_cast<unsigned int*>(ws), H, N, D, {rows_vec_ok(x0, s0, sizeof(T), D), rows_vec_ok(x1, s1, sizeof(T), D)}};
+    Max2Params prm{{x0, x1}, {s0, s1}, reinterpret_cast<unsigned long long*>(ws), H, N, D, {rows_vec_ok(x0, s0, sizeof(T), D), rows_vec_ok(x1, s1, sizeof(T), D)}};
     dim3 grid(npart, B * H, 2), block(256);
     if (need <= 4) hipLaunchKernelGGL((normalize_max2_kernel<T, 4>), grid, block, 0, stream, prm);
     else if (need <= 8) hipLaunchKernelGGL((normalize_max2_kernel<T, 8>), grid, block, 0, stream, prm);
@@ -759,15 +770,15 @@ static int launch_stats2_t(const void* x0, Strides3 s0, const void* x1, Strides3
     else if (need <= 32) hipLaunchKernelGGL((normalize_max2_kernel<T, 32>), grid, block, 0, stream, prm);
     else hipLaunchKernelGGL((normalize_max2_kernel<T, 64>), grid, block, 0, stream, prm);
     hipLaunchKernelGGL(normalize_finish_partials_kernel, dim3((2 * B * H + 255) / 256), dim3(256), 0, stream,
-                       reinterpret_cast<const unsigned int*>(ws), npart, inv0, inv1, B * H);
+                       reinterpret_cast<const unsigned long long*>(ws), npart, inv0, inv1, B * H, nstar0, nstar1);
     return (int)hipGetLastError();
 }
 int launch_normalize_stats2(const void* x0, Strides3 s0, const void* x1, Strides3 s1, int dtype, float* inv0, float* inv1, int B, int H,
-                            int N, int D, void* ws, hipStream_t stream) {
+                            int N, int D, void* ws, hipStream_t stream, int* nstar0, int* nstar1) {
     switch (dtype) {
-        case FASTMAX_F32: return launch_stats2_t<float>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
-        case FASTMAX_BF16: return launch_stats2_t<bf16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
-        case FASTMAX_F16: return launch_stats2_t<f16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream);
+        case FASTMAX_F32: return launch_stats2_t<float>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream, nstar0, nstar1);
+        case FASTMAX_BF16: return launch_stats2_t<bf16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream, nstar0, nstar1);
+        case FASTMAX_F16: return launch_stats2_t<f16_t>(x0, s0, x1, s1, inv0, inv1, B, H, N, D, ws, stream, nstar0, nstar1);
     }
     return FASTMAX_E_BAD_DTYPE;
 }

@@ -414,9 +414,8 @@ int launch_split_states_stats(const FwdArgs& a, const SplitPlan& plan, int dp) {
 int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp) {
     const LinearmaxStats& st = *a.stats;
     if (plan.nseg > 1) return launch_split_states_stats(a, plan, dp);
-    // the paired statistics pass does not determine the rows n*: nstar_q / nstar_k keep what the caller put there (-1)
     return launch_normalize_stats2(a.q, a.qs, a.k, a.ks, a.prob.in_dtype, st.inv_q, st.inv_k, a.prob.B, a.prob.H, a.prob.Nq, a.prob.D,
-                                   st.partials, a.stream);
+                                   st.partials, a.stream, st.nstar_q, st.nstar_k);
 }
 
 }  // namespace fastmax

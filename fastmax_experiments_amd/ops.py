@@ -213,8 +213,7 @@ def linearmax_forward_fused(q, k, v, return_stats=False, train=False):
     """Masked first-order linearmax with the prologue fused into the matrix-core kernel.
     Returns None when the shape / dtype is not covered (the caller then uses the unfused route).
     ``train``: -> (o, g, inv_q, inv_k, states, k_nstar) for linearmax_backward (states = the forward's workspace when it holds
-    the sequence split's prefix states, else None; nstar (2, B*H) = per head the row of q / of k that attains the max-norm, or
-    None when the statistics did not ride on the state pass)."""
+    the sequence split's prefix states, else None; nstar (2, B*H) = per head the row of q / of k that attains the max-norm)."""
     L = _lib.lib()
     dev = q.device
     B, H, N, D = q.shape
@@ -245,8 +244,7 @@ def linearmax_forward_fused(q, k, v, return_stats=False, train=False):
         if KEEP_STATES and wsb is not None:
             nb = L.fastmax_hip_forward_state_bytes(ctypes.byref(prob), q.data_ptr(), _strides(q), k.data_ptr(), _strides(k),
                                                    v.data_ptr(), _strides(v), o.data_ptr())
-        split = L.fastmax_hip_forward_workspace(ctypes.byref(prob)) > 0           # the statistics rode on the state pass
-        return o, g, stats[0], stats[1], (wsb if 0 < nb <= wsb.numel() else None), (nstar if split else None)
+        return o, g, stats[0], stats[1], (wsb if 0 < nb <= wsb.numel() else None), nstar
     return (o, stats[0], stats[1]) if return_stats else o
 
 

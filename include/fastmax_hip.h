@@ -199,9 +199,8 @@ int fastmax_hip_linearmax_forward_auto(const fastmax_problem* prob,
                                        int* q_nstar, int* k_nstar,
                                        void* o, float* g,
                                        void* workspace, size_t workspace_bytes, void* stream);
-/*      q_nstar / k_nstar (B*H ints each, or NULL): the row that attains the max-norm, per head -- written only when the
- *      statistics rode on the state pass (the caller pre-sets -1); fastmax_hip_linearmax_backward's fused prologue backward
- *      needs k_nstar.                                                                                                      */
+/*      q_nstar / k_nstar (B*H ints each, or NULL): the row that attains the max-norm, per head (the statistics are kept as
+ *      (value, row) keys); fastmax_hip_linearmax_backward's fused prologue backward needs them.                           */
 
 /*      Training route of the same branch (masked, p = 1): the backward of fastmax_hip_linearmax_forward_auto.  q, k are the RAW
  *      tensors and q_inv_norm / k_inv_norm what the forward left; the linear-time scans apply the prologue while staging (as the

@@ -724,10 +724,10 @@ def test_linearmax_training_route_with_the_prologue_inside_the_scans(shape, dt, 
     """masked p=1 linearmax with gradients, N >= 512: ONE autograd node on the raw q, k, v (fastmax_hip_linearmax_forward_auto +
     fastmax_hip_linearmax_backward: the scans normalise while staging, no normalised copy is stored) against the C oracle's scan
     on float64-normalised inputs with the chain rule through the prologue, and against the two-node route (normalize_cast +
-    fastmax) it replaces.  D = 128 exists for bf16 only (other dtypes keep the two-node route there: also checked).  With the
-    sequence split (few heads) the forward's statistics carry the rows n* and BOTH scan kernels apply the prologue's backward
-    to their own tiles (dq, dk leave as gradients wrt the raw tensors; one-row fix-ups add the dL/dM term); the last shape has
-    enough heads to run without the split: there the prologue's backward stays its own pass."""
+    fastmax) it replaces.  D = 128 exists for bf16 only (other dtypes keep the two-node route there: also checked).
+    The forward's statistics carry the rows n* and BOTH scan kernels apply the prologue's backward to their own tiles (dq, dk
+    leave as gradients wrt the raw tensors; one-row fix-ups add the dL/dM term) -- with the sequence split (few heads: statistics
+    on the state pass) and without it (the last shape: paired statistics pass)."""
     import importlib
     fh = importlib.import_module("fastmax_experiments_amd.attention_mechanisms.fastmax_hack")      # the module, not the function
     from oracle import c_oracle, fastmax_oracle as orc

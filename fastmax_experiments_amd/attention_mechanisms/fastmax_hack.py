@@ -87,7 +87,7 @@ class _LinearmaxP1(torch.autograd.Function):
         o, g, inv_q, inv_k, states, nstar = r
         ctx.save_for_backward(q, k, v, o, g, inv_q, inv_k)
         ctx.states, ctx.rep = states, rep
-        ctx.nstar = nstar if (rep == 1 and FUSED_PROLOGUE_BWD) else None
+        ctx.nstar = nstar if FUSED_PROLOGUE_BWD else None
         return o
 
     @staticmethod
@@ -99,13 +99,13 @@ class _LinearmaxP1(torch.autograd.Function):
             B, G, N, D = k.shape
             kv = k.view(B * G, 1, N, D).expand(B * G, rep, N, D)
         go = ops._prep(go.to(q.dtype), q.device)
-        fused = ctx.nstar is not None        # both scan kernels apply the prologue's backward to their tiles
-        dqn, dkn, dv = ops.linearmax_backward(q, kv, v, o, g, go, inv_q, inv_k, ctx.states, nstar=ctx.nstar, fuse=FUSED_PROLOGUE_BWD)
+        # the scan kernels apply the prologue's backward to their own tiles: both sides, or with grouped-query heads the q side
+        # only (the group's dk' are summed by the prologue's backward pass below)
+        fuse = 0 if ctx.nstar is None else (FUSED_PROLOGUE_BWD if rep == 1 else (FUSED_PROLOGUE_BWD & 2))
+        dqn, dkn, dv = ops.linearmax_backward(q, kv, v, o, g, go, inv_q, inv_k, ctx.states, nstar=ctx.nstar, fuse=fuse)
         ctx.states = ctx.nstar = None
-        if fused and FUSED_PROLOGUE_BWD == 3:
-            return dqn, dkn, dv, None
-        dq = ops.normalize_backward(q, dqn, inv_q.view(q.shape[0], q.shape[1]), 1)
-        if fused:
+        dq = dqn if fuse & 2 else ops.normalize_backward(q, dqn, inv_q.view(q.shape[0], q.shape[1]), 1)
+        if fuse & 1:
             dk = dkn
         elif rep > 1:
             B, G, N, D = k.shape

@@ -413,7 +413,7 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob, const void* q, c
               workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream)};
     a.qscale = q_inv_norm;
     a.kscale = k_inv_norm;
-    a.fuse_prologue = ((flags & 1) && k_nstar ? 1 : 0) | ((flags & 3) == 3 && k_nstar && q_nstar ? 2 : 0);
+    a.fuse_prologue = ((flags & 1) && k_nstar ? 1 : 0) | ((flags & 2) && q_nstar ? 2 : 0);
     a.k_nstar = k_nstar;
     a.q_nstar = q_nstar;
     const SplitPlan plan = split_plan(*prob);

@@ -333,7 +333,9 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && NW == 4) ? 2 : 1) void bwd_p1
 // dK, dV: grid = B*H, block = 256; chunks are walked from the last to the first
 // ------------------------------------------------------------------------------------------------
 // NW = 8: wave (wk = w & 3, hf = w >> 2) owns the 16 keys of tile wk and the column half hf of dK, dV and of the R2 state
-template <int DP, typename TIN, int NW, bool NORM, bool BUF, bool FUSEK = false>
+// FUSEK: 0 none; 1 the prologue's backward for k on the dK tile + the shared sum T; 2 the sum T only (grouped-query heads: dk' is
+// summed over the group by the prologue's own backward pass, but the q side is finished in the dQ kernel and needs T)
+template <int DP, typename TIN, int NW, bool NORM, bool BUF, int FUSEK = 0>
 __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW == 4) ? 2 : 1) void bwd_p1_dkv_kernel(LinBwdParams prm) {
     static_assert(!FUSEK || NORM, "the fused prologue backward belongs to the linearmax route");
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
@@ -592,14 +594,16 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
                     kdot = fmaf(dkacc[t][i], y[i], kdot);
                 }
             }
-            krs += __shfl_xor(krs, 16, 64);
-            krs += __shfl_xor(krs, 32, 64);
-            if constexpr (NW == 8) {
-                if (q4 == 0) reinterpret_cast<float*>(smem + RSUM)[16 * w + r] = krs;
+            if constexpr (FUSEK == 1) {
+                krs += __shfl_xor(krs, 16, 64);
+                krs += __shfl_xor(krs, 32, 64);
+                if constexpr (NW == 8) {
+                    if (q4 == 0) reinterpret_cast<float*>(smem + RSUM)[16 * w + r] = krs;
+                }
             }
         }
         __syncthreads();                                             // B2
-        if constexpr (FUSEK) {
+        if constexpr (FUSEK == 1) {
             if constexpr (NW == 8) krs += reinterpret_cast<const float*>(smem + RSUM)[16 * (w ^ 4) + r];     // the other column half
             const float kmean = krs * invD, kinv = prm.kscale[bh];     // read here: one more live value across the loop spills at D = 128
 #pragma unroll
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(64 * NW, (InTraits<TIN>::NP == 1 && DP == 64 && NW 
     }
 }
 
-template <int DP, typename TIN, bool NORM, bool BUF, bool FUSEK, bool FUSEQ = false>
+template <int DP, typename TIN, bool NORM, bool BUF, int FUSEK, bool FUSEQ = false>
 static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream, const fastmax_problem& prob) {
     constexpr int NP = InTraits<TIN>::NP, EPL = InTraits<TIN>::EPL;
     // four waves where two workgroups fit a CU (bf16 D <= 64: both kernels; two-part D <= 64: dQ only), eight waves
@@ -669,8 +673,10 @@ static int launch_lin_bwd_b(const LinBwdParams& prm, int BH, hipStream_t stream,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kkv, dim3(BH * prm.nseg), dim3(64 * NWKV), lds_kv, stream, prm);
-    if constexpr (FUSEK) {
-        int rc = launch_normalize_fixadd(prm.k, prm.ks, prob.in_dtype, prm.kscale, prm.kpart_dot, prm.k_nstar, prm.nseg, prob.B, prob.H,
+    if constexpr (FUSEK != 0) {
+        int rc = 0;
+        if constexpr (FUSEK == 1)
+            rc = launch_normalize_fixadd(prm.k, prm.ks, prob.in_dtype, prm.kscale, prm.kpart_dot, prm.k_nstar, prm.nseg, prob.B, prob.H,
                                          prm.N, prm.D, prm.dk, stream);
         if constexpr (FUSEQ) {
             if (rc) return rc;
@@ -689,11 +695,13 @@ static int launch_lin_bwd_t(const LinBwdParams& prm, int BH, hipStream_t stream,
     const bool buf = quad32_span_ok(prm.qs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.ks.sn, prm.N, prm.D, es) &&
                      quad32_span_ok(prm.vs.sn, prm.N, prm.D, es) && quad32_span_ok(prm.gos.sn, prm.N, prm.D, es);
     if constexpr (NORM) {
-        if (prm.kpart_dot && prm.q_nstar)
-            return buf ? launch_lin_bwd_b<DP, TIN, true, true, true, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, true, true>(prm, BH, stream, prob);
-        if (prm.kpart_dot) return buf ? launch_lin_bwd_b<DP, TIN, true, true, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, true>(prm, BH, stream, prob);
+        if (prm.kpart_dot && prm.q_nstar && prm.k_nstar)
+            return buf ? launch_lin_bwd_b<DP, TIN, true, true, 1, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, 1, true>(prm, BH, stream, prob);
+        if (prm.kpart_dot && prm.q_nstar)          // q side only (grouped-query heads)
+            return buf ? launch_lin_bwd_b<DP, TIN, true, true, 2, true>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, 2, true>(prm, BH, stream, prob);
+        if (prm.kpart_dot) return buf ? launch_lin_bwd_b<DP, TIN, true, true, 1>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, true, false, 1>(prm, BH, stream, prob);
     }
-    return buf ? launch_lin_bwd_b<DP, TIN, NORM, true, false>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false, false>(prm, BH, stream, prob);
+    return buf ? launch_lin_bwd_b<DP, TIN, NORM, true, 0>(prm, BH, stream, prob) : launch_lin_bwd_b<DP, TIN, NORM, false, 0>(prm, BH, stream, prob);
 }
 
 bool lin_bwd_supported(const fastmax_problem& p);
@@ -729,9 +737,9 @@ int launch_bwd_lin(const BwdArgs& a) {
     LinBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
                      cbuf, a.prob.H, a.prob.Nq, a.prob.D, a.prob.in_dtype, a.prob.out_dtype, a.prob.a,
                      fstate, rstate, plan.nseg, plan.cps, a.qscale, a.kscale, nullptr, nullptr, nullptr};
-    if ((a.fuse_prologue & 1) && a.qscale && a.kscale && a.k_nstar) {
+    if (a.fuse_prologue && a.qscale && a.kscale) {
         prm.kpart_dot = reinterpret_cast<float*>(ws + coff + 2 * sbytes);
-        prm.k_nstar = a.k_nstar;
+        if (a.fuse_prologue & 1) prm.k_nstar = a.k_nstar;
         if (a.fuse_prologue & 2) prm.q_nstar = a.q_nstar;
     }
     const int BH = a.prob.B * a.prob.H;

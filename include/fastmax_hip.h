@@ -223,8 +223,9 @@ int fastmax_hip_linearmax_backward(const fastmax_problem* prob,
                                    const void* fwd_states, size_t fwd_state_bytes, int flags, void* stream);
 /*      flags bit 0 (needs k_nstar with every entry >= 0): dk leaves as the gradient wrt the RAW k (the dK/dV kernel applies
  *      inv (g - mean_D g) to its tile and a one-row fix-up adds the dL/dM term to row n*): no normalize_backward call for k.
- *      Only when every query head has its own k head.  flags bit 1 (with bit 0, needs q_nstar): the same for dq / q -- the
- *      number both fix-ups need, sum_ij dS_ij s_ij, is one and the same and comes out of the dK/dV kernel.                */
+ *      Only when every query head has its own k head.  flags bit 1 (needs q_nstar): the same for dq / q -- the number both
+ *      fix-ups need, sum_ij dS_ij s_ij, is one and the same and comes out of the dK/dV kernel; bit 1 alone is the form for
+ *      grouped-query heads (k a stride-0 view of the key heads: dk is summed over the group by the caller's prologue pass).  */
 
 
 /* ---- the operator's neighbours in CausalSelfAttention.forward (lit_gpt/model.py:397-425) in one pass:

@@ -14,6 +14,7 @@ per byte with the first element in the high nibble.  Parity with bitsandbytes' o
 Fused forward (csrc/nf4_lora.hip):  y = x deq(W)^T + bias + (dropout(x) A^T) (scaling * scatter(B))^T
 """
 import ctypes
+import logging
 import os
 import weakref
 import math
@@ -274,6 +275,16 @@ class NF4Linear(nn.Module):
         return qlora_linear(x, self, None, None)
 
 
+_announced = set()
+
+
+def _announce_once(key: str, msg: str) -> None:
+    """a route other than the hand-written one was taken for a reason the caller did not ask for: say so, once per reason"""
+    if key not in _announced:
+        _announced.add(key)
+        logging.getLogger(__name__).warning(msg)
+
+
 # ---------------------------------------------------------------------------------------------
 # the fused op
 # ---------------------------------------------------------------------------------------------
@@ -327,6 +338,10 @@ class _QLoRALinearFn(torch.autograd.Function):
             ctx.dims = (M, N, K, dt)
             return y
         if ctx.dense:
+            if QLORA_ROUTE != "library":
+                _announce_once(f"dense-lib-{N % 64}-{K % 64}-{0 if ea is None else ea.shape[1]}",
+                               f"QLoRA linear ({M} x {K}) -> {N}: the tile GEMM needs N and K to be multiples of 64 and a LoRA operand of "
+                               "16 or 32 columns; this layer runs as HIP decode + library GEMM")
             y = x2 @ (wdense if wdense is not None else _dense_weight(wq, scales, N, K)).t()
             if ea is not None:
                 y.addmm_(ea, eb.t())

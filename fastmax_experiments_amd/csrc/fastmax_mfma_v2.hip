@@ -262,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_d64_f32_v2_kernel(MfmaV2Params 
             qh[1] = pack8(h[2], h[3]); ql[1] = pack8(l[2], l[3]);
         }
         __builtin_amdgcn_sched_barrier(0);                           // Q is consumed BEFORE the refills below are issued
-        if (c + 1 < c_end) issue_q(rq, n0 + C, (w + c + 1) & 3);
 
         // ---- (b) K, V registers -> bf16 hi/lo images; exact fp32 column sums -------------------------------
         {
@@ -284,7 +283,13 @@ __global__ __launch_bounds__(256, 2) void fwd_p1_d64_f32_v2_kernel(MfmaV2Params 
             *reinterpret_cast<f32x4*>(smem + PARTV + (srow * 64 + 4 * scol) * 4) = cv;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < c_end) issue_kv(rk, rv, n0 + C);                 // refill this register set: one chunk ahead
+        // refill both register sets one chunk ahead, Q first (it is consumed first next time).  Q used to be requested right after
+        // its consumption, i.e. BEFORE the K / V registers were staged: the memory counter is in-order, so the wait for the last
+        // K / V piece (vmcnt(0)) also waited for the four Q loads issued a moment earlier -- their latency exposed in every chunk
+        if (c + 1 < c_end) {
+            issue_q(rq, n0 + C, (w + c + 1) & 3);
+            issue_kv(rk, rv, n0 + C);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // B1: images + partial sums visible
 

@@ -2,6 +2,8 @@
 #pragma once
 #include "fastmax_common.h"
 
+#include <type_traits>
+
 namespace fastmax {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -415,10 +417,10 @@ template <bool BUF, typename TIN, int NPASS, int RPP> struct ScanLoader;
 // thread's row / column (shared by all loaders) with one 24-bit multiply-add and one add per load; the row stride, the tile
 // stride and the descriptor are scalars.  BufTileLoader keeps NPASS offsets per loader: at four loaders the D = 128 dK/dV
 // kernel spilled them, and a scratch reload in front of the prefetch loads is a full memory round trip per chunk.
-template <typename TIN, int NPASS, int RPP> struct ScanLoader<true, TIN, NPASS, RPP> {
+template <typename TIN, int NPASS, int RPP, int AUX> struct BufTileLoaderLean {
     __amdgpu_buffer_rsrc_t rs;
     int row_bytes, base_off, srow;
-    __device__ __forceinline__ ScanLoader(const TIN* base, int64_t sn, int nrows, int D, int, int srow_, int scol) : srow(srow_) {
+    __device__ __forceinline__ BufTileLoaderLean(const TIN* base, int64_t sn, int nrows, int D, int srow_, int scol) : srow(srow_) {
         constexpr int EPL = InTraits<TIN>::EPL;
         row_bytes = __builtin_amdgcn_readfirstlane((int)sn * (int)sizeof(TIN));
         const int nrec = nrows > 0 ? (nrows - 1) * row_bytes + D * (int)sizeof(TIN) : 0;
@@ -433,9 +435,16 @@ template <typename TIN, int NPASS, int RPP> struct ScanLoader<true, TIN, NPASS, 
         asm volatile("" : "+v"(sr));
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
-            r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)__umul24((unsigned)(sr + ps * RPP), (unsigned)row_bytes) + base_off + t, 0, 2);
+            r[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)__umul24((unsigned)(sr + ps * RPP), (unsigned)row_bytes) + base_off + t, 0, AUX);
     }
 };
+template <typename TIN, int NPASS, int RPP> struct ScanLoader<true, TIN, NPASS, RPP> : BufTileLoaderLean<TIN, NPASS, RPP, 2> {
+    __device__ __forceinline__ ScanLoader(const TIN* b, int64_t sn, int nrows, int D, int, int srow, int scol)
+        : BufTileLoaderLean<TIN, NPASS, RPP, 2>(b, sn, nrows, D, srow, scol) {}
+};
+// tile kernels: the offsets kept in registers where registers are plentiful (single-part operands), re-formed where they are not
+template <typename TIN, int NPASS, int RPP>
+using TileKernelLoader = std::conditional_t<InTraits<TIN>::NP == 2, BufTileLoaderLean<TIN, NPASS, RPP, 0>, BufTileLoader<TIN, NPASS, RPP>>;
 template <typename TIN, int NPASS, int RPP> struct ScanLoader<false, TIN, NPASS, RPP> : TileLoader<TIN, NPASS, RPP, true> {
     __device__ __forceinline__ ScanLoader(const TIN* b, int64_t sn, int nrows, int D, int DP, int srow, int scol)
         : TileLoader<TIN, NPASS, RPP, true>(b, sn, nrows, D, DP, srow, scol) {}

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, MB) void bwd32_dq_kernel(Quad32BwdParams p
     const int klim = causal ? min(myq, Nk - 1) : Nk - 1;
 
     u32x4 rk[NPASS], rv[NPASS];
-    const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
+    const TileKernelLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
     auto request = [&](int kt) __attribute__((always_inline)) {
         kload.load(kt, rk);
         vload.load(kt, rv);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NW, (DP == 64 && InTraits<TIN>::NP == 1 && NW 
 
     u32x4 rq[NPASS], rg[NPASS];
     float rcw = 0.f;
-    const BufTileLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, srow, scol), gload(gb, D, Nq, D, srow, scol);
+    const TileKernelLoader<TIN, NPASS, RPP> qload(qb, prm.qs.sn, Nq, D, srow, scol), gload(gb, D, Nq, D, srow, scol);
     auto request = [&](int it) __attribute__((always_inline)) {
         qload.load(it, rq);
         gload.load(it, rg);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, (quad32_min_blocks<DP, TIN, NPP, NW, QB>()
     }
 
     u32x4 rk[NPASS], rv[NPASS];
-    const BufTileLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
+    const TileKernelLoader<TIN, NPASS, RPP> kload(kb, prm.ks.sn, Nk, D, srow, scol), vload(vb, prm.vs.sn, Nk, D, srow, scol);
     auto request = [&](int kt) __attribute__((always_inline)) {
         kload.load(kt, rk);
         vload.load(kt, rv);

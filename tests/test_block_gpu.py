@@ -423,21 +423,23 @@ def test_flat_grad_bucket_with_bf16_parameters_on_device():
     assert a.grad is None and float(bucket.flat.abs().sum()) == 0.0 and b.grad.data_ptr() == bucket._views[1].data_ptr()
 
 
-def test_dp_micro_batch_replayed_as_hip_graph_matches_eager():
+@pytest.mark.parametrize("alg,T", [("fastmax", 256), ("linearmax", 1024)])
+def test_dp_micro_batch_replayed_as_hip_graph_matches_eager(alg, T):
     """`DataParallelStepper.capture`: one micro-batch (QLoRA attention stack + lm-head loss, forward + backward into the flat
     bucket) recorded as a HIP graph and replayed with new batches -- same losses and the same parameters after the optimizer
-    steps as the eager step (the kernels are deterministic: bitwise equality)."""
+    steps as the eager step (the kernels are deterministic: bitwise equality).  linearmax at 1024 tokens: the one-node route with
+    the prologue and its backward inside the linear-time scans (statistics on the state pass, row fix-ups) is what gets recorded."""
     from fastmax_experiments_amd import dp, finetune_step
     from fastmax_experiments_amd.attention_block import build_rope_cache
     dev = torch.device("cuda")
-    T, mb, accum = 256, 2, 2
+    mb, accum = 2, 2
     g = torch.Generator(device=dev).manual_seed(5)
     x = torch.randn(2 * accum, mb, T, 128, device=dev, generator=g).to(torch.bfloat16)
     tgt = torch.randint(0, 512, (2 * accum, mb, T), device=dev, generator=g)
     finals, losses = [], []
     for graph in (False, True):
         torch.manual_seed(0)
-        model = finetune_step.AttentionStack("pythia-14m", 2, "fastmax", vocab=512, lora_dropout=0.0).prepare(dev)   # no dropout: bitwise
+        model = finetune_step.AttentionStack("pythia-14m", 2, alg, vocab=512, lora_dropout=0.0).prepare(dev)   # no dropout: bitwise
         cos, sin = (t.to(torch.bfloat16) for t in build_rope_cache(T, model.rope_n_elem, device=dev))
         params = dp.trainable_lora_parameters(model)
         opt = torch.optim.AdamW(params, lr=1e-3)

@@ -756,6 +756,25 @@ def test_linearmax_training_route_with_the_prologue_inside_the_scans(shape, dt, 
             assert rel_err(got, w) < tol, (fused, name)
 
 
+def test_linearmax_training_route_on_strided_storage():
+    """q, k, v stored (B, N, H, D) and handed over as (B, H, N, D) views (what a fused QKV projection produces): the one-node route
+    reads them through their strides -- same bits as on contiguous copies, forward and all three gradients"""
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    B, H, N, D = 2, 4, 1024, 64
+    g = torch.Generator().manual_seed(21)
+    base = [torch.randn(B, N, H, D, generator=g).to(torch.bfloat16).cuda() for _ in range(3)]
+    go = torch.randn(B, H, N, D, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for strided in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in base]
+        q, k, v = (t.transpose(1, 2) if strided else t.transpose(1, 2).contiguous() for t in leaves)
+        o = fastmax_hack(q, k, v, p=1, mask=True)
+        o.backward(go)
+        res.append([o.detach()] + [t.grad.clone() for t in leaves])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_grouped_linearmax_training_route_without_normalised_copies():
     """grouped-query heads on the one-node route: q, v (B*G, rep, N, D) (v a stride-0 group view), K at its G heads -- same
     output and gradients as the two-node grouped route"""

@@ -28,6 +28,8 @@ int select(const fastmax_problem& p) {
     if (p.path == FASTMAX_PATH_QUADRATIC) return FASTMAX_PATH_QUADRATIC;
     if (p.path == FASTMAX_PATH_QUADRATIC_MFMA) return quad_mfma_supported(p) ? FASTMAX_PATH_QUADRATIC_MFMA : FASTMAX_E_BAD_SHAPE;
     const bool lin = (p.p == 1 && p.causal);
+    // unmasked first order at sizes where a pass over K, V + one D x D product per query row beats the O(N_q N_k) tiles
+    if (p.p == 1 && !p.causal && (p.path == FASTMAX_PATH_AUTO || p.path == FASTMAX_PATH_MFMA) && unmasked_lin_supported(p)) return FASTMAX_PATH_MFMA;
     // head sizes above 128 (pythia-1b, Gemma, stablelm-3b in lit_gpt/config.py): tile kernels only -- no D x D state is carried
     if (p.D > 128) {
         if (p.path == FASTMAX_PATH_RECURRENT || p.path == FASTMAX_PATH_MFMA) return FASTMAX_E_BAD_SHAPE;
@@ -141,6 +143,7 @@ int fastmax_hip_select_path(const fastmax_problem* prob) {
 size_t fastmax_hip_forward_workspace(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
     if (select(*prob) != FASTMAX_PATH_MFMA) return 0;
+    if (!prob->causal) return unmasked_lin_workspace(*prob);
     return split_workspace_bytes(*prob, prob->D <= 64 ? 64 : 128);
 }
 
@@ -157,13 +160,14 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
                         aligned16(v, v_strides, prob->in_dtype) && !(reinterpret_cast<uintptr_t>(o) & 15);
         if (!ok) {
             if (prob->path == path) return FASTMAX_E_ALIGNMENT;          // the caller forced this family
-            path = path == FASTMAX_PATH_MFMA ? FASTMAX_PATH_RECURRENT : FASTMAX_PATH_QUADRATIC;
+            path = path == FASTMAX_PATH_MFMA ? (prob->causal ? FASTMAX_PATH_RECURRENT : FASTMAX_PATH_QUADRATIC) : FASTMAX_PATH_QUADRATIC;
         }
     }
     FwdArgs a{*prob, q, k, v, st(q_strides), st(k_strides), st(v_strides), o, g, workspace, workspace_bytes,
               reinterpret_cast<hipStream_t>(stream)};
     switch (path) {
         case FASTMAX_PATH_MFMA:
+            if (!prob->causal) return launch_fwd_unmasked_p1(a);
             if (mfma_p1_supported(*prob)) return launch_fwd_mfma_p1(a);
             if (mfma_d128_2p_supported(*prob)) return launch_fwd_mfma_d128_2p(a, nullptr, nullptr);
             return use_bf16_kernel(*prob) ? launch_fwd_mfma_bf16(a, nullptr, nullptr) : launch_fwd_mfma_gen(a, nullptr, nullptr);
@@ -183,7 +187,7 @@ size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
 size_t fastmax_hip_forward_state_bytes(const fastmax_problem* prob, const void* q, const int64_t* q_strides, const void* k,
                                        const int64_t* k_strides, const void* v, const int64_t* v_strides, const void* o) {
     if (validate(prob) || !q || !k || !v || !o || !q_strides || !k_strides || !v_strides) return 0;
-    if (select(*prob) != FASTMAX_PATH_MFMA) return 0;
+    if (select(*prob) != FASTMAX_PATH_MFMA || !prob->causal) return 0;
     // the same layout rule as fastmax_hip_forward: anything else takes a kernel without a sequence split
     if (!(aligned16(q, q_strides, prob->in_dtype) && aligned16(k, k_strides, prob->in_dtype) && aligned16(v, v_strides, prob->in_dtype) &&
           !(reinterpret_cast<uintptr_t>(o) & 15)))

@@ -147,6 +147,9 @@ SplitPlan split_plan(const fastmax_problem& p);
 size_t split_workspace_bytes(const fastmax_problem& p, int dp);
 int launch_split_states(const FwdArgs& a, const SplitPlan& plan, int dp, const float* kscale);
 int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp);
+bool unmasked_lin_supported(const fastmax_problem& p);
+size_t unmasked_lin_workspace(const fastmax_problem& p);
+int launch_fwd_unmasked_p1(const FwdArgs& a);
 int launch_normalize_fixadd(const void* x, Strides3 xs, int dtype, const float* inv_norm, const float* part_dot,
                             const int* nstar, int nblk, int B, int H, int N, int D, void* gx, hipStream_t stream);
 int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);

@@ -418,4 +418,126 @@ int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp) 
                                    st.partials, a.stream, st.nstar_q, st.nstar_k);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Unmasked first order in linear time (fastmax.py:258-271 / fastmax_hack.py:6-33 without the (N,D,D) temporaries):
+//     o_i = (S1 + a S2^T q_i) / (g0 + a q_i . ksum)      with the TOTAL sums S2 = sum_j k_j v_j^T, S1 = sum_j v_j, ksum = sum_j k_j
+// = the state pass above over all of K, V (per-segment records + inclusive prefix: the last record is the total) and one
+// D x D product per query row.  What the reference runs at inference with a KV cache (model.py:460-487: mask = False, the whole
+// prompt against the padded cache).  N_q and N_k are independent.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_one(void* base, int dtype, int64_t idx, float val) {
+    if (dtype == FASTMAX_F32) reinterpret_cast<float*>(base)[idx] = val;
+    else if (dtype == FASTMAX_BF16) reinterpret_cast<uint16_t*>(base)[idx] = f32_to_bf16_bits(val);
+    else reinterpret_cast<_Float16*>(base)[idx] = (_Float16)val;
+}
+struct ApplyParams {
+    const void* q;
+    Strides3 qs;
+    const float* total;       // [B*H] records [S2 (DP x DP) | S1 | ksum], record stride rec_stride floats
+    int64_t rec_stride;
+    void* o;
+    float* g;
+    int H, Nq, D, out_dtype;
+    float a, g0;
+};
+// block = 256 threads = 4 waves, each wave walks rows; lane owns output column(s) lane (+ 64) and keeps that column of S2 in
+// registers; the row's q values are broadcast from LDS
+template <typename TIN, int DP>
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void unmasked_p1_apply_kernel(ApplyParams prm) {
+    constexpr int NC = DP / 64, RB = 128;                          // rows per block
+    __shared__ float q_s[4][DP];
+    __shared__ float ks_s[DP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const float* rec = prm.total + (int64_t)bh * prm.rec_stride;
+    float S[NC][DP], s1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int m = 0; m < DP; ++m) S[c][m] = rec[m * DP + 64 * c + lane];
+        s1[c] = rec[DP * DP + 64 * c + lane];
+    }
+    if (tid < DP) ks_s[tid] = rec[DP * DP + DP + tid];
+    __syncthreads();
+    const int row0 = blockIdx.x * RB;
+    const int D = prm.D;
+    for (int r = row0 + w; r < min(prm.Nq, row0 + RB); r += 4) {
+        const TIN* qrow = row_ptr<TIN>(prm.q, prm.qs.sb, prm.qs.sh, prm.qs.sn, b, h, r);
+        float gp = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int m = 64 * c + lane;
+            const float qv = m < D ? prm.a * to_float(qrow[m]) : 0.f;
+            q_s[w][m] = qv;
+            gp = fmaf(qv, ks_s[m], gp);
+        }
+        const float gval = prm.g0 + wave_sum(gp);
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = s1[c];
+        // q_s[w] was written by this wave's own lanes: a wave-level fence is enough before it is read back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < DP; ++m) {                               // fully unrolled: S stays in registers
+            const float qm = q_s[w][m];                              // broadcast read
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(qm, S[c][m], acc[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / gval;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (64 * c + lane < D) store_one(prm.o, prm.out_dtype, ((int64_t)bh * prm.Nq + r) * D + 64 * c + lane, acc[c] * inv);
+        if (lane == 0 && prm.g) prm.g[(int64_t)bh * prm.Nq + r] = gval;
+    }
+}
+
+static SplitPlan unmasked_plan(const fastmax_problem& p) {
+    const int BH = p.B * p.H, nchunks = (p.Nk + 63) / 64;
+    int nseg = (512 + BH - 1) / BH;
+    if (nseg > nchunks / 4) nseg = nchunks / 4;
+    if (nseg > 31) nseg = 31;
+    if (nseg < 1) nseg = 1;
+    const int cps = (nchunks + nseg - 1) / nseg;
+    nseg = (nchunks + cps - 1) / cps;
+    return SplitPlan{nseg + 1, cps};            // the state kernel computes segments 0 .. nseg-2 of a plan: one more than needed
+}
+bool unmasked_lin_supported(const fastmax_problem& p) {
+    const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
+    // worth it once the O(N_q N_k) tiles outgrow a pass over K, V and a D x D product per query row
+    return p.p == 1 && !p.causal && (p.D % epl) == 0 && p.D <= 128 && p.Nk >= 512 && p.Nq >= 64 && (int64_t)p.B * p.H <= 65535;
+}
+size_t unmasked_lin_workspace(const fastmax_problem& p) {
+    const int dp = p.D <= 64 ? 64 : 128;
+    const SplitPlan plan = unmasked_plan(p);
+    return sizeof(float) * (size_t)p.B * p.H * (plan.nseg - 1) * ((size_t)dp * dp + 2 * dp);
+}
+int launch_fwd_unmasked_p1(const FwdArgs& a) {
+    if (!unmasked_lin_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
+    if (!a.workspace || a.workspace_bytes < unmasked_lin_workspace(a.prob)) return FASTMAX_E_WORKSPACE;
+    const int dp = a.prob.D <= 64 ? 64 : 128;
+    const SplitPlan plan = unmasked_plan(a.prob);
+    FwdArgs fa = a;
+    fa.prob.Nq = a.prob.Nk;                       // the state pass walks the KEY rows
+    fa.stats = nullptr;
+    int rc = launch_split_states(fa, plan, dp, nullptr);
+    if (rc) return rc;
+    const int nrec = plan.nseg - 1, rec = dp * dp + 2 * dp;
+    ApplyParams prm{a.q, a.qs, reinterpret_cast<const float*>(a.workspace) + (int64_t)(nrec - 1) * rec, (int64_t)nrec * rec, a.o, a.g,
+                    a.prob.H, a.prob.Nq, a.prob.D, a.prob.out_dtype, a.prob.a, a.prob.g0};
+    const dim3 grid((a.prob.Nq + 127) / 128, a.prob.B * a.prob.H), block(256);
+#define APPLY(T)                                                                                                   \
+    if (dp == 64) hipLaunchKernelGGL((unmasked_p1_apply_kernel<T, 64>), grid, block, 0, a.stream, prm);            \
+    else hipLaunchKernelGGL((unmasked_p1_apply_kernel<T, 128>), grid, block, 0, a.stream, prm)
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: APPLY(float); break;
+        case FASTMAX_BF16: APPLY(bf16_t); break;
+        case FASTMAX_F16: APPLY(f16_t); break;
+        default: return FASTMAX_E_BAD_DTYPE;
+    }
+#undef APPLY
+    return (int)hipGetLastError();
+}
+
 }  // namespace fastmax

@@ -126,6 +126,36 @@ def test_decode_shapes_matrix_core_tiles():
             assert rel_err(o.float().cpu().numpy(), ro) < tol, D
 
 
+@pytest.mark.parametrize("dt,tf,tb", [(torch.float32, TOL_FWD, TOL_BWD), (torch.bfloat16, 8e-3, 2.5e-2), (torch.float16, 2e-3, 5e-3)])
+@pytest.mark.parametrize("nq,nk,D", [(700, 1100, 64), (64, 4096, 128), (2048, 2048, 64), (300, 520, 48), (1000, 640, 128)])
+def test_unmasked_first_order_in_linear_time(nq, nk, D, dt, tf, tb):
+    """mask=False, p=1 at sizes where the O(N_q N_k) tiles lose: o_i = (S1 + a S2^T q_i) / (g0 + a q_i.ksum) from ONE pass over K, V
+    (the sequence-split state kernel, all segments) and a D x D product per query row -- what the reference's KV-cache inference
+    calls (model.py:460-487: the whole prompt against the cache, mask=False).  Forward against the dense fp64 oracle for both
+    denominators' constants (N_q in fastmax.py:271, N_k in fastmax_hack.py:21), and the gradients (tile kernels fed with this
+    forward's o and g) against the C oracle."""
+    from attention_mechanisms.fastmax import fastmax
+    from attention_mechanisms.fastmax_hack import fastmax_hack
+    from fastmax_experiments_amd import _lib, ops
+    from oracle import c_oracle, fastmax_oracle as orc
+    g = torch.Generator().manual_seed(nq + nk + D)
+    q, go = (torch.randn(2, 3, nq, D, generator=g).to(dt) for _ in range(2))
+    k, v = (torch.randn(2, 3, nk, D, generator=g).to(dt) for _ in range(2))
+    qq, kk, vv = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    assert ops.selected_path(qq, kk, 1, False) == _lib.PATH_MFMA
+    o = fastmax(qq, kk, vv, mask=False, p=1)
+    ro, _ = orc.fastmax_fwd_dense(q.float().numpy(), k.float().numpy(), v.float().numpy(), mask=False, p=1)
+    assert rel_err(o.detach().float().cpu().numpy(), ro) < (tf if o.dtype == dt else max(tf, TOL_FWD))
+    o.backward(go.cuda().to(o.dtype))
+    e = c_oracle.bwd(q.float().numpy(), k.float().numpy(), v.float().numpy(), go.float().numpy(), mask=False, p=1)
+    for t, rr, n in zip((qq, kk, vv), e, ("dq", "dk", "dv")):
+        assert rel_err(t.grad.float().cpu().numpy(), rr, atol=2e-2) < tb, n
+    with torch.no_grad():
+        oh = fastmax_hack(q.cuda(), k.cuda(), v.cuda(), p=1, mask=False)
+    rh = orc.linearmax_fwd(q.double().numpy(), k.double().numpy(), v.double().numpy(), p=1, mask=False)
+    assert rel_err(oh.float().cpu().numpy(), np.asarray(rh)) < max(4 * tf, 2e-3)
+
+
 def test_c1_baseline_config():
     from attention_mechanisms.fastmax import fastmax
     d, _ = load_golden("c1_fastmax_p1_masked_fp32")

@@ -180,7 +180,9 @@ int fastmax_hip_forward(const fastmax_problem* prob, const void* q, const int64_
 size_t fastmax_hip_backward_workspace(const fastmax_problem* prob) {
     if (validate(prob)) return 0;
     const size_t a = bwd_quadratic_workspace(*prob), b = lin_bwd_workspace(*prob);
-    const size_t c = scan_bwd_supported(*prob) ? scan_bwd_workspace(*prob) : 0;
+    size_t c = scan_bwd_supported(*prob) ? scan_bwd_workspace(*prob) : 0;
+    const size_t d = unmasked_lin_bwd_workspace(*prob);
+    if (d > c) c = d;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
@@ -217,6 +219,9 @@ int fastmax_hip_backward_with_states(const fastmax_problem* prob, const void* q,
                          !((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) |
                             reinterpret_cast<uintptr_t>(dv)) & 15);
     if (!mfma_ok) return launch_bwd_quadratic(a);
+    // p=1 unmasked at sizes where totals + row-wise D x D products beat the O(N_q N_k) tiles
+    if (prob->path != FASTMAX_PATH_QUADRATIC_MFMA && unmasked_lin_bwd_supported(*prob) && !(reinterpret_cast<uintptr_t>(o) & 15))
+        return launch_bwd_unmasked_p1(a);
     // p=1 masked: linear-time scans (carried D x D state) unless the caller asks for the tile kernels
     const bool lin = prob->path != FASTMAX_PATH_QUADRATIC_MFMA && lin_bwd_supported(*prob) && prob->in_dtype == prob->out_dtype &&
                      !(reinterpret_cast<uintptr_t>(o) & 15);

@@ -150,12 +150,17 @@ int linearmax_stats_and_states(const FwdArgs& a, const SplitPlan& plan, int dp);
 bool unmasked_lin_supported(const fastmax_problem& p);
 size_t unmasked_lin_workspace(const fastmax_problem& p);
 int launch_fwd_unmasked_p1(const FwdArgs& a);
+int launch_bwd_unmasked_p1(const BwdArgs& a);
+size_t unmasked_lin_bwd_workspace(const fastmax_problem& p);
+bool unmasked_lin_bwd_supported(const fastmax_problem& p);
+int launch_bwd_prep_c(const BwdArgs& a, float* cbuf);
 int launch_normalize_fixadd(const void* x, Strides3 xs, int dtype, const float* inv_norm, const float* part_dot,
                             const int* nstar, int nblk, int B, int H, int N, int D, void* gx, hipStream_t stream);
 int launch_fwd_mfma_d128_2p(const FwdArgs& a, const float* qscale, const float* kscale);
 bool mfma_d128_2p_supported(const fastmax_problem& p);
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
-                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale = nullptr);
+                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale = nullptr,
+                         int first_seg = 1);
 size_t lin_bwd_workspace(const fastmax_problem& p);
 int launch_fwd_quad_mfma(const FwdArgs& a);
 bool quad_mfma_supported(const fastmax_problem& p);

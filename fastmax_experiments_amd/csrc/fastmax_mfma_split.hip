@@ -26,6 +26,8 @@ struct StateParams {
     Strides3 qs;
     unsigned long long* partials;   // [2 (q, k)][B*H][pw] keys: (bits of max ||row - mean||^2) << 32 | ~row
     int BH, pw;
+    int rs_first = 1;         // RS: the first segment a block computes (1: the causal scans never need segment 0's own sums;
+                              // 0: the unmasked backward wants the total)
 };
 constexpr int STAT_LT = 4;    // chunks (of 64 rows) per statistics-only block
 
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q4 = lane >> 4;
     const int nchunks_all = (prm.N + 63) / 64;
-    int bh = blockIdx.y, seg = (int)blockIdx.x + (RS ? 1 : 0);
+    int bh = blockIdx.y, seg = (int)blockIdx.x + (RS ? prm.rs_first : 0);
     bool statq = false, maxonly = false;                                    // block-uniform
     int light_c0 = 0, word = 0;
     if constexpr (NORM == 2) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(4 * DP, 2) void p1_state_kernel(StateParams prm) {
         if (maxonly) return;
     }
     // record = [S2 (DP x DP, row-major [m][d]) | S1 (DP) | ksum (DP)]
-    float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg - (RS ? 1 : 0)) * (DP * DP + 2 * DP);
+    float* rec = prm.state + ((int64_t)bh * (prm.nseg - 1) + seg - (RS ? prm.rs_first : 0)) * (DP * DP + 2 * DP);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         reinterpret_cast<float*>(smem + PARTK)[srow * DP + scol * EPL + e] = ck[e];
@@ -360,8 +362,8 @@ static int launch_state_d(const StateParams& prm, int BH, int dp, hipStream_t st
 
 // reverse-scan states of the linear-time backward: q in the K role, grad_o (scaled by 1/g) in the V role
 int launch_split_rstates(const void* q, Strides3 qs, const void* go, Strides3 gos, const float* g, const float* c, float* state,
-                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale) {
-    StateParams prm{q, go, qs, gos, state, qscale, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr, 0, 0};
+                         const fastmax_problem& p, const SplitPlan& plan, int dp, hipStream_t stream, const float* qscale, int first_seg) {
+    StateParams prm{q, go, qs, gos, state, qscale, p.H, p.Nq, p.D, plan.nseg, plan.cps, g, c, nullptr, Strides3{}, nullptr, 0, 0, first_seg};
     const int BH = p.B * p.H;
     if (qscale) {
         switch (p.in_dtype) {
@@ -493,16 +495,71 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void unmasked_p1_apply_kerne
     }
 }
 
-static SplitPlan unmasked_plan(const fastmax_problem& p) {
-    const int BH = p.B * p.H, nchunks = (p.Nk + 63) / 64;
-    int nseg = (512 + BH - 1) / BH;
-    if (nseg > nchunks / 4) nseg = nchunks / 4;
-    if (nseg > 31) nseg = 31;
-    if (nseg < 1) nseg = 1;
-    const int cps = (nchunks + nseg - 1) / nseg;
-    nseg = (nchunks + cps - 1) / cps;
-    return SplitPlan{nseg + 1, cps};            // the state kernel computes segments 0 .. nseg-2 of a plan: one more than needed
+// The backward of the same function, also from totals (fastmax.py:383-691 unmasked, without the O(N_q N_k) tiles):
+//     w_i = 1/g_i, c_i = G_i.o_i, ghat_i = w_i G_i, e_i = -w_i c_i
+//     dQ_i = a w_i S2 G_i + a e_i ksum                     S2 = sum_j k_j v_j^T, ksum = sum_j k_j          (totals over the keys)
+//     dK_j = a (R2 v_j + rq)                               R2 = sum_i q_i ghat_i^T, rq = sum_i q_i e_i     (totals over the queries)
+//     dV_j = R1 + a R2^T k_j                               R1 = sum_i ghat_i
+// = two state passes (the forward's kernel over K, V; its reverse-scan variant over q, G with the row factors) and three
+// row-wise D x D products.  out_r[c] = sb_r bias[c] + sx_r sum_m M(c, m) x_r[m]; TRANS: M(c, m) = rec[m][c], else rec[c][m].
+struct Apply2Params {
+    const void* x;
+    Strides3 xs;
+    const float* total;
+    int64_t rec_stride;
+    void* out;
+    const float *g, *c;       // MODE 0 (dQ): row factors
+    int H, N, D, out_dtype, bias_slot;    // bias_slot: 1 = the "S1" vector of the record, 2 = the "ksum" vector
+    float a;
+};
+template <typename TIN, int DP, bool TRANS, int MODE>
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void unmasked_p1_apply2_kernel(Apply2Params prm) {
+    constexpr int NC = DP / 64, RB = 128;
+    __shared__ float x_s[4][DP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.y, b = bh / prm.H, h = bh % prm.H;
+    const float* rec = prm.total + (int64_t)bh * prm.rec_stride;
+    float S[NC][DP], bias[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int m = 0; m < DP; ++m) S[c][m] = TRANS ? rec[m * DP + 64 * c + lane] : rec[(64 * c + lane) * DP + m];
+        bias[c] = rec[DP * DP + (prm.bias_slot == 2 ? DP : 0) + 64 * c + lane];
+    }
+    const int row0 = blockIdx.x * RB, D = prm.D;
+    for (int r = row0 + w; r < min(prm.N, row0 + RB); r += 4) {
+        const TIN* xrow = row_ptr<TIN>(prm.x, prm.xs.sb, prm.xs.sh, prm.xs.sn, b, h, r);
+        float sx = prm.a, sb = MODE == 2 ? 1.0f : prm.a;             // MODE 1 (dK): a, a;  MODE 2 (dV): a, 1
+        if constexpr (MODE == 0) {                                    // dQ: a w_i, a e_i
+            const float wi = 1.0f / prm.g[(int64_t)bh * prm.N + r];
+            sx = prm.a * wi;
+            sb = -prm.a * wi * prm.c[(int64_t)bh * prm.N + r];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int m = 64 * c + lane;
+            x_s[w][m] = m < D ? to_float(xrow[m]) : 0.f;
+        }
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < DP; ++m) {
+            const float xm = x_s[w][m];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(xm, S[c][m], acc[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (64 * c + lane < D) store_one(prm.out, prm.out_dtype, ((int64_t)bh * prm.N + r) * D + 64 * c + lane, fmaf(sx, acc[c], sb * bias[c]));
+    }
 }
+
+static SplitPlan unmasked_plan_rows(const fastmax_problem& p, int rows);
+static SplitPlan unmasked_plan(const fastmax_problem& p) { return unmasked_plan_rows(p, p.Nk); }   // segments 0 .. nseg-2 of the plan cover all keys
 bool unmasked_lin_supported(const fastmax_problem& p) {
     const int epl = p.in_dtype == FASTMAX_F32 ? 4 : 8;
     // worth it once the O(N_q N_k) tiles outgrow a pass over K, V and a D x D product per query row
@@ -537,6 +594,70 @@ int launch_fwd_unmasked_p1(const FwdArgs& a) {
         default: return FASTMAX_E_BAD_DTYPE;
     }
 #undef APPLY
+    return (int)hipGetLastError();
+}
+
+static SplitPlan unmasked_plan_rows(const fastmax_problem& p, int rows) {
+    const int BH = p.B * p.H, nchunks = (rows + 63) / 64;
+    int nseg = (512 + BH - 1) / BH;
+    if (nseg > nchunks / 4) nseg = nchunks / 4;
+    if (nseg > 31) nseg = 31;
+    if (nseg < 1) nseg = 1;
+    const int cps = (nchunks + nseg - 1) / nseg;
+    nseg = (nchunks + cps - 1) / cps;
+    return SplitPlan{nseg + 1, cps};
+}
+static size_t align16b(size_t x) { return (x + 15) & ~(size_t)15; }
+// workspace = [ c (B,H,Nq) | records over the keys | records over the queries ]
+bool unmasked_lin_bwd_supported(const fastmax_problem& p) {
+    // the reverse-state pass exists for D <= 64 (every dtype) and for bf16 up to 128 (as in the causal linear-time backward)
+    return unmasked_lin_supported(p) && (p.D <= 64 || p.in_dtype == FASTMAX_BF16);
+}
+size_t unmasked_lin_bwd_workspace(const fastmax_problem& p) {
+    if (!unmasked_lin_bwd_supported(p)) return 0;
+    const int dp = p.D <= 64 ? 64 : 128;
+    const size_t rec = sizeof(float) * ((size_t)dp * dp + 2 * dp), BH = (size_t)p.B * p.H;
+    return align16b(sizeof(float) * BH * p.Nq) + align16b(BH * (unmasked_plan_rows(p, p.Nk).nseg - 1) * rec) +
+           align16b(BH * (unmasked_plan_rows(p, p.Nq).nseg - 1) * rec);
+}
+template <typename TIN>
+static void launch_apply2(const Apply2Params& prm, int dp, int mode, int BH, hipStream_t stream) {
+    const dim3 grid((prm.N + 127) / 128, BH), block(256);
+#define AP2(DPV, TR, MD) hipLaunchKernelGGL((unmasked_p1_apply2_kernel<TIN, DPV, TR, MD>), grid, block, 0, stream, prm)
+    if (dp == 64) { if (mode == 0) AP2(64, false, 0); else if (mode == 1) AP2(64, false, 1); else AP2(64, true, 2); }
+    else { if (mode == 0) AP2(128, false, 0); else if (mode == 1) AP2(128, false, 1); else AP2(128, true, 2); }
+#undef AP2
+}
+int launch_bwd_unmasked_p1(const BwdArgs& a) {
+    const fastmax_problem& p = a.prob;
+    if (!unmasked_lin_bwd_supported(p)) return FASTMAX_E_BAD_SHAPE;
+    if (!a.workspace || a.workspace_bytes < unmasked_lin_bwd_workspace(p)) return FASTMAX_E_WORKSPACE;
+    const int dp = p.D <= 64 ? 64 : 128, BH = p.B * p.H;
+    const size_t rec = (size_t)dp * dp + 2 * dp;
+    const SplitPlan pk = unmasked_plan_rows(p, p.Nk), pq = unmasked_plan_rows(p, p.Nq);
+    char* ws = reinterpret_cast<char*>(a.workspace);
+    float* cbuf = reinterpret_cast<float*>(ws);
+    float* srec = reinterpret_cast<float*>(ws + align16b(sizeof(float) * (size_t)BH * p.Nq));
+    float* rrec = reinterpret_cast<float*>(reinterpret_cast<char*>(srec) + align16b(sizeof(float) * (size_t)BH * (pk.nseg - 1) * rec));
+    int rc = launch_bwd_prep_c(a, cbuf);                                   // c_i = G_i . o_i
+    if (rc) return rc;
+    FwdArgs fa{p, a.q, a.k, a.v, a.qs, a.ks, a.vs, nullptr, nullptr, srec, sizeof(float) * (size_t)BH * (pk.nseg - 1) * rec, a.stream};
+    fa.prob.Nq = p.Nk;                                                     // totals over the key rows
+    rc = launch_split_states(fa, pk, dp, nullptr);
+    if (rc) return rc;
+    // totals over the query rows: R2 = sum q ghat^T, R1 = sum ghat, rq = sum q e (every segment, suffix-summed: record 0)
+    rc = launch_split_rstates(a.q, a.qs, a.grad_o, a.gos, a.g, cbuf, rrec, p, pq, dp, a.stream, nullptr, 0);
+    if (rc) return rc;
+    const float* stot = srec + (size_t)(pk.nseg - 2) * rec;
+    Apply2Params pdq{a.grad_o, a.gos, stot, (int64_t)(pk.nseg - 1) * (int64_t)rec, a.dq, a.g, cbuf, p.H, p.Nq, p.D, p.in_dtype, 2, p.a};
+    Apply2Params pdk{a.v, a.vs, rrec, (int64_t)(pq.nseg - 1) * (int64_t)rec, a.dk, nullptr, nullptr, p.H, p.Nk, p.D, p.in_dtype, 2, p.a};
+    Apply2Params pdv{a.k, a.ks, rrec, (int64_t)(pq.nseg - 1) * (int64_t)rec, a.dv, nullptr, nullptr, p.H, p.Nk, p.D, p.in_dtype, 1, p.a};
+    switch (p.in_dtype) {
+        case FASTMAX_F32: launch_apply2<float>(pdq, dp, 0, BH, a.stream); launch_apply2<float>(pdk, dp, 1, BH, a.stream); launch_apply2<float>(pdv, dp, 2, BH, a.stream); break;
+        case FASTMAX_BF16: launch_apply2<bf16_t>(pdq, dp, 0, BH, a.stream); launch_apply2<bf16_t>(pdk, dp, 1, BH, a.stream); launch_apply2<bf16_t>(pdv, dp, 2, BH, a.stream); break;
+        case FASTMAX_F16: launch_apply2<f16_t>(pdq, dp, 0, BH, a.stream); launch_apply2<f16_t>(pdk, dp, 1, BH, a.stream); launch_apply2<f16_t>(pdv, dp, 2, BH, a.stream); break;
+        default: return FASTMAX_E_BAD_DTYPE;
+    }
     return (int)hipGetLastError();
 }
 

@@ -460,6 +460,19 @@ int launch_bwd_quad32(const BwdArgs& a) {
     return e ? e : launch_bwd_quad32_main(a);
 }
 
+// c_i = G_i . o_i alone (the linear-time unmasked backward needs nothing else from the prep pass)
+int launch_bwd_prep_c(const BwdArgs& a, float* cbuf) {
+    QuadBwdParams prm{a.q, a.k, a.v, a.o, a.grad_o, a.g, a.qs, a.ks, a.vs, a.gos, a.dq, a.dk, a.dv,
+                      cbuf, a.prob.H, a.prob.Nq, a.prob.Nk, a.prob.D, a.prob.causal, a.prob.in_dtype, a.prob.out_dtype, a.prob.a};
+    switch (a.prob.in_dtype) {
+        case FASTMAX_F32: launch_prep<float>(prm, a.prob.B * a.prob.H, a.stream); break;
+        case FASTMAX_BF16: launch_prep<bf16_t>(prm, a.prob.B * a.prob.H, a.stream); break;
+        case FASTMAX_F16: launch_prep<f16_t>(prm, a.prob.B * a.prob.H, a.stream); break;
+        default: return FASTMAX_E_BAD_DTYPE;
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_bwd_quad_mfma(const BwdArgs& a) {
     if (!quad_mfma_bwd_supported(a.prob)) return FASTMAX_E_BAD_SHAPE;
     if (a.workspace_bytes < sizeof(float) * (size_t)a.prob.B * a.prob.H * a.prob.Nq || !a.workspace) return FASTMAX_E_WORKSPACE;

@@ -132,8 +132,9 @@ def test_unmasked_first_order_in_linear_time(nq, nk, D, dt, tf, tb):
     """mask=False, p=1 at sizes where the O(N_q N_k) tiles lose: o_i = (S1 + a S2^T q_i) / (g0 + a q_i.ksum) from ONE pass over K, V
     (the sequence-split state kernel, all segments) and a D x D product per query row -- what the reference's KV-cache inference
     calls (model.py:460-487: the whole prompt against the cache, mask=False).  Forward against the dense fp64 oracle for both
-    denominators' constants (N_q in fastmax.py:271, N_k in fastmax_hack.py:21), and the gradients (tile kernels fed with this
-    forward's o and g) against the C oracle."""
+    denominators' constants (N_q in fastmax.py:271, N_k in fastmax_hack.py:21), and the gradients -- from totals as well
+    (dQ_i = a w_i S2 G_i + a e_i ksum, dK_j = a (R2 v_j + rq), dV_j = R1 + a R2^T k_j; fp32 / fp16 above D = 64: tile kernels fed with
+    this forward's o and g) -- against the C oracle."""
     from attention_mechanisms.fastmax import fastmax
     from attention_mechanisms.fastmax_hack import fastmax_hack
     from fastmax_experiments_amd import _lib, ops

@@ -42,6 +42,9 @@ for dt in (torch.bfloat16, torch.float32):
             for train in (False, True):
                 cases.append((op, *shape, dt, p, True, train))
 cases.append(("fastmax", 1, 4, 600, 64, torch.bfloat16, 2, False, True))
+cases.append(("fastmax", 2, 3, 1100, 64, torch.bfloat16, 1, False, True))          # unmasked first order from totals
+cases.append(("fastmax", 1, 2, 900, 128, torch.float32, 1, False, True))
+cases.append(("linearmax", 1, 4, 1024, 64, torch.bfloat16, 1, False, False))
 bad = 0
 for case in cases:
     poison(0)
